@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""masked-forward-passes/sec benchmark (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the workload of BASELINE configs[2]
+("ResNet-101, 512 masks/image x 128 images, 1 MI355X"): per image, K0 stages its 512 masked
+copies, the network scores them, 512 scores stay on the device.  With N GPUs every rank runs its
+own 128 images (weak scaling; N=8 is BASELINE configs[3], 1024 images) and ONE RCCL all-gather of
+the per-mask scores closes the step.  Inputs (images, label map, mask-vectors, weights) are
+resident in HBM before the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_EVERY = 8               # HIP-event bracketing on every 8th image batch of the timed region
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--images", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--masks", type=int, default=512, help="masks per image (= forward batch)")
+    ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, n_masks):
+    """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per
+    superpixel) on this box's host cores, bounded sample of the same workload."""
+    from network_interpretation_imagenet_amd import synth
+    from oracle import scorer
+    sd = synth.make_state_dict(arch)
+    img = synth.make_images(1, kind="noise")[0]
+    x = scorer.to_tensor_normalize(img)
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(n_masks, 196)
+    scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[:1], 0)    # warm the thread pool
+    t0 = time.perf_counter()
+    scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, 0)
+    dt = time.perf_counter() - t0
+    return {"value": n_masks / dt, "unit": "masked-forward-passes/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s)" % (arch, n_masks, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    import __graft_entry__ as g
+    g.build()
+    from network_interpretation_imagenet_amd import shard, synth
+    from network_interpretation_imagenet_amd.engine import MaskedForwardEngine
+
+    n_img, n_mask = args.images, args.masks
+    eng = MaskedForwardEngine(args.arch, max_batch=n_mask, device=local_rank)
+    eng.load_state_dict(synth.make_state_dict(args.arch))
+    # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
+    # per-image Bernoulli(0.4) mask-vectors, labels = unmasked argmax (the reference's correctness gate)
+    imgs = torch.from_numpy(synth.make_images(n_img, seed=1234 + rank, kind="noise")).to(dev)
+    seg = torch.from_numpy(synth.grid_segments()).to(dev)
+    onoff = torch.from_numpy(synth.random_onoff(n_img * n_mask, 196, seed=4321 + rank)).view(n_img, n_mask, 196).to(dev)
+    ones = torch.ones(1, 196, dtype=torch.uint8, device=dev)
+    labels = []
+    for i in range(n_img):
+        eng.stage_masks(imgs[i], seg, ones, 0)
+        _s, p = eng.forward(1, torch.zeros(1, dtype=torch.int32, device=dev))
+        labels.append(p)
+    labels = torch.cat(labels)
+    label_rows = labels.view(n_img, 1).expand(n_img, n_mask).contiguous()
+    scores = torch.empty(n_img, n_mask, dtype=torch.float32, device=dev)
+    total = world * n_img * n_mask
+
+    def step(profile):
+        for i in range(n_img):
+            prof = profile and (i % PROFILE_EVERY == 0)
+            if prof:
+                eng.profile(True)
+            eng.stage_masks(imgs[i], seg, onoff[i], 0)
+            s, _p = eng.forward(n_mask, label_rows[i])
+            scores[i] = s
+            if prof:
+                eng.profile(False)
+        if world > 1:
+            return shard.all_gather_blocks(scores.view(-1), total)
+        return scores.view(-1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    prof = {"ms": {}, "launches": {}}
+    for _ in range(args.steps):
+        out = step(True)
+        part = eng.collect_profile()        # waits for this step's last recorded event (the pool is bounded)
+        for key in ("ms", "launches"):
+            for k, v in part[key].items():
+                prof[key][k] = prof[key].get(k, 0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.numel() == total and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        value = total * args.steps / dt
+        conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
+        n_conv_layers = len(eng.layers)
+        batches_profiled = conv_n / n_conv_layers if n_conv_layers else 0
+        flops_per_batch = eng.flops_per_forward * n_mask
+        roofline = None
+        if conv_n:
+            # dominant kernel = conv_f16x3_kernel (all conv/fc launches).  achieved = algorithmic FLOPs
+            # of the launches / their summed HIP-event durations; MFMA-issued FLOPs are 3x algorithmic.
+            achieved = flops_per_batch * batches_profiled / (conv_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "conv_f16x3_kernel", "launches": conv_n,
+                        "avg_launch_us": conv_ms * 1e3 / conv_n,
+                        "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,
+                        "other_kernels_ms_per_batch": {k: v / max(batches_profiled, 1) for k, v in prof["ms"].items() if k != "conv"}}
+        line = {
+            "metric": "masked-forward-passes/sec (224x224, %s)" % args.arch,
+            "value": value, "unit": "masked-forward-passes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
+            "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
+            "config": {"workload": "%s, %d masks/image x %d images per GPU (BASELINE configs[2]; x%d GPUs)" % (args.arch, n_mask, n_img, world),
+                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": n_mask,
+                       "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
+            "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline(args.arch, args.cpu_masks) if (world == 1 and args.cpu_masks > 0) else None,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

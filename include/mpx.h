@@ -1,0 +1,157 @@
+/* mpx.h -- C-ABI of the MI355X masked-perturbation scoring engine ("mpx").
+ *
+ * Drop-in boundary for ONE path of LiliMeng/network_interpretation_imagenet: for one
+ * 224x224 image, apply M superpixel on/off mask-vectors to the normalised image, run one
+ * ResNet forward per mask, return softmax(logits)[label] and argmax(logits) per mask.
+ * The reference has no FFI layer (it is 100 % Python); every entry point below names the
+ * reference lines it replaces.  Paths are relative to the reference repository root.
+ *
+ * Conventions
+ *   - Plain C types only.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Pointers marked DEV are device pointers owned by the caller; HOST are host pointers.
+ *     The engine never frees or retains caller memory; it owns only its workspace.
+ *   - Every function returns 0 on success, a positive hipError_t, or a negative MPX_E_* code,
+ *     never throws, never exits, and (unless stated) does not synchronise the stream.
+ *   - Activations between kernels live in HBM as TWO fp16 planes in NHWC order ("split-fp16":
+ *     x ~= hi + lo, 22 significant bits, 4 bytes per element like fp32).  Convolutions run on
+ *     the fp16 MFMA pipe as hi*hi + hi*lo + lo*hi with fp32 accumulation.
+ *   - One engine per process per GPU.  Calls on one engine must not overlap from two threads.
+ */
+#ifndef MPX_H
+#define MPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPX_IMG 224          /* n = 224, generate_gp_training_data_imagenet.py:84-88 */
+#define MPX_IMG_PAD 230      /* 3-pixel zero border, the 7x7 stem's padding=3, stored explicitly */
+#define MPX_NUM_CLASSES 1000
+
+enum {
+    MPX_E_ARG = -1,      /* bad argument (null pointer, shape, range) */
+    MPX_E_STATE = -2,    /* weights missing, batch larger than max_batch, ... */
+    MPX_E_NOMEM = -3,
+    MPX_E_INTERNAL = -4
+};
+
+/* arch_id = the torchvision ResNet depth the reference selects with `-a` / `--arch`
+ * (generate_gp_training_data_imagenet.py:45,579): 18, 34, 50, 101 or 152. */
+typedef struct mpx_engine mpx_engine;
+
+typedef struct mpx_conv_desc {
+    char name[48];       /* torchvision state_dict prefix of the conv ("layer3.4.conv2", "fc") */
+    char bn_name[48];    /* prefix of its BatchNorm ("layer3.4.bn2"); "" for fc */
+    int32_t cin, cout, ksize, stride, pad;
+    int32_t hin, hout;   /* square spatial sizes at 224x224 input */
+    int32_t relu;        /* ReLU in the epilogue */
+    int32_t residual;    /* adds the block identity before the ReLU */
+    int32_t k_packed;    /* K of the packed [cout_pad][k_packed] fp16 weight planes */
+    int32_t cout_pad;    /* rows of the packed planes (multiple of 128) */
+} mpx_conv_desc;
+
+/* ---- engine life cycle -------------------------------------------------------------------
+ * replaces: models.__dict__[args.arch](pretrained=True); model.cuda(); model.eval()
+ *           (generate_gp_training_data_imagenet.py:579-580,159).  Allocates the whole workspace
+ *           (input staging for max_batch masked images, activation planes, logits) once. */
+int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out);
+int mpx_destroy(mpx_engine* h);
+const char* mpx_last_error(const mpx_engine* h);   /* "" if none; valid until next call */
+int mpx_max_batch(const mpx_engine* h);
+size_t mpx_workspace_bytes(const mpx_engine* h);
+
+/* ---- topology / weights ------------------------------------------------------------------
+ * Layer i in [0, mpx_num_convs): every conv in forward order, then "fc" as the last entry. */
+int mpx_num_convs(const mpx_engine* h);
+int mpx_conv_info(const mpx_engine* h, int i, mpx_conv_desc* out);
+
+/* replaces: the state_dict tensors torchvision loads (same line as above).  HOST pointers, f32:
+ * w = conv weight OIHW [cout][cin][k][k]; gamma/beta/mean/var = BatchNorm weight/bias/
+ * running_mean/running_var [cout]; eps = 1e-5 for torchvision.  For the last entry ("fc"):
+ * w = fc.weight [1000][C], beta = fc.bias, gamma/mean/var = NULL.  Packs on the host
+ * (mpx_pack_conv_weights) and uploads synchronously. */
+int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamma,
+                         const float* beta, const float* mean, const float* var, float eps);
+int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has weights */
+
+/* Host-only packer (no GPU needed; what mpx_set_conv_weights runs before the upload).
+ * Produces the fp16 planes w_hi/w_lo [cout_pad][k_packed] (k order = (ky,kx,ci), ci fastest;
+ * for the 7x7 stem k = ky*32 + px*4 + c over the NHWC4 padded input), each output channel
+ * multiplied by 2^e so that max|w| lies in [512,1024), and the fp32 epilogue
+ * scale = gamma/sqrt(var+eps) * 2^-e, shift = beta - mean*gamma/sqrt(var+eps).
+ * All outputs are HOST buffers sized from mpx_conv_desc (uint16_t = raw fp16 bits). */
+int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma,
+                          const float* beta, const float* mean, const float* var, float eps,
+                          uint16_t* w_hi, uint16_t* w_lo, float* scale, float* shift);
+
+/* ---- K0: mask-apply + normalise ----------------------------------------------------------
+ * replaces: transforms.ToTensor + Normalize (generate_gp_training_data_imagenet.py:598-599),
+ *           the per-segment pixel-mask build (:234-237), `input[0].numpy().copy() * mask`
+ *           (:240) and the per-mask H2D copy (:242-245).
+ * Exactly one of img_u8_hwc (DEV u8[224][224][3], raw pixels; normalised in-kernel as
+ * (u8/255 - mean_c)/std_c in fp32) and img_f32_chw (DEV f32[3][224][224], already normalised,
+ * what the reference's val_loader yields) is non-NULL.
+ * seg: DEV i32[224][224], labels in [0,S) (rank in np.unique(segments) order).
+ * onoff: DEV u8[M][S]; onoff[m][s] != 0 keeps superpixel s in mask m (normalise THEN mask:
+ * removed pixels become 0.0 in normalised space).
+ * Writes masked image m into engine input slot slot0+m (slot0+M <= max_batch) and, if
+ * out_f32_nchw (DEV f32[M][3][224][224]) is non-NULL, the reference-layout tensor as well. */
+int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const float* img_f32_chw,
+                             const int32_t* seg, const uint8_t* onoff, int M, int S,
+                             const float mean[3], const float std[3], int slot0,
+                             float* out_f32_nchw, void* stream);
+
+/* ---- K1/K2: conv + BN (+ residual) (+ ReLU), one layer ------------------------------------
+ * replaces: one nn.Conv2d -> nn.BatchNorm2d (-> `out += identity`) (-> nn.ReLU) group inside
+ *           model(masked_img_tensor) (generate_gp_training_data_imagenet.py:246).
+ * in_hi|lo, res_hi|lo, out_hi|lo: DEV fp16 NHWC planes [B][h][w][c] (layer 0 reads the engine's padded
+ * NHWC4 input staging instead: pass in_hi = in_lo = NULL).  res_* may be NULL.
+ * For the last entry ("fc") out_hi/out_lo are ignored and out_f32 (DEV f32[B][1000]) is written;
+ * for every other layer out_f32 must be NULL. */
+int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo,
+                    const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
+                    float* out_f32, int B, void* stream);
+
+/* ---- K3: maxpool 3x3 s2 p1 (nn.MaxPool2d inside the same forward), NHWC split planes ------ */
+int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,
+                     void* out_lo, int B, int hin, int c, void* stream);
+
+/* ---- K4a: global average pool [B][hw][c] -> [B][c] (nn.AvgPool2d(7) + view) ---------------- */
+int mpx_global_avgpool(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,
+                       void* out_lo, int B, int hw, int c, void* stream);
+
+/* ---- K4b: softmax + gather(label) + argmax ------------------------------------------------
+ * replaces: F.softmax(mask_output) ... [0][label] (bayesian_active_learning_imagenet.py:196-198)
+ *           and mask_output.data.max(1, keepdim=True)[1] (generate_gp_training_data_imagenet.py:248).
+ * logits DEV f32[B][1000]; label DEV i32[B]; score DEV f32[B]; pred DEV i32[B]. */
+int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* label,
+                            float* score, int32_t* pred, int B, void* stream);
+
+/* ---- whole network -------------------------------------------------------------------------
+ * replaces: mask_output = model(masked_img_tensor) + score extraction for B masked images
+ *           already staged in input slots [0,B) by mpx_mask_apply_normalize.
+ * logits_out (DEV f32[B][1000]) may be NULL. */
+int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred,
+                float* logits_out, int B, void* stream);
+
+/* ---- introspection for tests / benchmarks --------------------------------------------------- */
+/* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4]. */
+int mpx_input_planes(const mpx_engine* h, void** hi, void** lo);
+/* When enabled, every kernel launch of mpx_forward / mpx_mask_apply_normalize is bracketed by
+ * HIP events on the launch stream (bounded pool; launches beyond it are not recorded). */
+int mpx_profile_enable(mpx_engine* h, int on);
+/* Synchronises the recorded events, ADDS their durations into the caller's arrays and clears
+ * the pool.  kind: 0 = conv (K1/K2), 1 = mask_apply_normalize (K0), 2 = pools (K3/K4a),
+ * 3 = head (K4b).  per_conv_ms (HOST f64[mpx_num_convs], may be NULL) gets the per-layer split. */
+int mpx_profile_collect(mpx_engine* h, double ms_by_kind[4], long long launches_by_kind[4],
+                        double* per_conv_ms);
+/* Algorithmic FLOPs (2*MAC, convs + fc) of one masked forward. */
+double mpx_flops_per_forward(const mpx_engine* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPX_H */

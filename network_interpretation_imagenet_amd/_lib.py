@@ -1,0 +1,75 @@
+"""ctypes binding of libmpx.so (include/mpx.h).  There is no CPU fallback: if the HIP library is
+missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpx.so")
+
+IMG = 224
+IMG_PAD = 230
+NUM_CLASSES = 1000
+
+
+class MpxError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("bn_name", C.c_char * 48),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
+                ("stride", C.c_int32), ("pad", C.c_int32), ("hin", C.c_int32),
+                ("hout", C.c_int32), ("relu", C.c_int32), ("residual", C.c_int32),
+                ("k_packed", C.c_int32), ("cout_pad", C.c_int32)]
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/mpx.h declares
+SIGNATURES = {
+    "mpx_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "mpx_destroy": (_i, [_vp]),
+    "mpx_last_error": (C.c_char_p, [_vp]),
+    "mpx_max_batch": (_i, [_vp]),
+    "mpx_workspace_bytes": (C.c_size_t, [_vp]),
+    "mpx_num_convs": (_i, [_vp]),
+    "mpx_conv_info": (_i, [_vp, _i, C.POINTER(ConvDesc)]),
+    "mpx_set_conv_weights": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f]),
+    "mpx_weights_complete": (_i, [_vp]),
+    "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
+    "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_maxpool3x3s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mpx_global_avgpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mpx_head_softmax_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_input_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mpx_profile_enable": (_i, [_vp, _i]),
+    "mpx_profile_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "mpx_flops_per_forward": (C.c_double, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmpx.so (built by __graft_entry__.build() / csrc/build.sh)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpxError("HIP extension %s not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = load().mpx_last_error(handle).decode() if handle else ""
+        raise MpxError("%s failed (rc=%d): %s" % (what, rc, msg))

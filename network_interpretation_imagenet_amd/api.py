@@ -1,0 +1,242 @@
+"""Reference-named entry points (drop-in for the GP / Bayesian-optimisation callers).
+
+Same names, argument orders and return types as the reference's callables
+(bayesian_active_learning_imagenet.py:116-298, generate_gp_training_data_imagenet.py:152-273,
+gp_superpixel_data_imagenet.py:186-350); `model` is a MaskedForwardEngine instead of a
+torchvision module, `val_loader` any iterable of (input f32[1,3,224,224], target[, gt_bbox]) and
+`criterion` is accepted and ignored exactly as the reference ignores its result
+(generate_gp_training_data_imagenet.py:194).  What changes is the cost: the reference pays one
+dataset scan + one segmentation + two batch-1 forwards per score; here every candidate window of
+an image is scored in ONE batched pass and later calls are table look-ups.
+
+Quirks deliberately left behind: no dataset re-scan per call, no
+`rm -rf ./masks` unless a mask_dir is passed, no float-valued PNG names.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import masks
+from .engine import BasePredictionWrong, MaskedForwardEngine, rank_segments, IMG
+
+__all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
+           "validate", "validate_summed", "score_masks", "default_segmenter", "img_show_u8",
+           "BasePredictionWrong", "configure"]
+
+_CONFIG = {"eval_img_index": 1, "num_mask_samples": 100, "segmenter": None, "mask_dir": None, "seed": None}
+_SESSIONS = {}
+_LAST = {"session": None}
+
+
+def configure(**kw):
+    """Stand-in for the reference's argparse globals (`args.eval_img_index`,
+    `args.num_mask_samples`; generate_gp_training_data_imagenet.py:78-81) plus the segmenter
+    (felzenszwalb, a CPU third-party step that stays outside the engine) and the optional PNG
+    output directory."""
+    for k, v in kw.items():
+        if k not in _CONFIG:
+            raise KeyError("unknown option %r (have %s)" % (k, sorted(_CONFIG)))
+        _CONFIG[k] = v
+    _SESSIONS.clear()
+
+
+def default_segmenter(img_u8_hwc):
+    """felzenszwalb(img_as_float(img_show), scale=100, sigma=0.5, min_size=50)
+    (generate_gp_training_data_imagenet.py:183).  skimage is a third-party CPU dependency of the
+    reference that this image does not ship; pass `segmenter=` to configure() when it is absent."""
+    try:
+        from skimage.segmentation import felzenszwalb
+        from skimage.util import img_as_float
+    except ImportError as e:   # pragma: no cover - depends on the environment
+        raise ImportError("skimage is not installed; configure(segmenter=callable) with a function "
+                          "u8[224,224,3] -> int[224,224]") from e
+    return felzenszwalb(img_as_float(img_u8_hwc), scale=100, sigma=0.5, min_size=50)
+
+
+def img_show_u8(input_chw):
+    """Min-max rescale to u8 HWC, the picture the reference segments
+    (generate_gp_training_data_imagenet.py:171-178; truncating astype)."""
+    img = np.array(input_chw, dtype=np.float32, copy=True).transpose(1, 2, 0)
+    img -= img.min()
+    img /= img.max()
+    img *= 255
+    return img.astype(np.uint8)
+
+
+def _as_int(target):
+    """target arrives as an int, tensor[1] (ImageFolder loader) or tensor[1,1] (localization loader)."""
+    return int(np.asarray(target).reshape(-1)[0])
+
+
+class SaliencySession:
+    """One (image, label, segmentation) with every window score cached."""
+
+    def __init__(self, engine, input_chw, target, segments=None, segmenter=None, check_base=True):
+        if not (hasattr(engine, "score_masks") and hasattr(engine, "predict")):
+            raise TypeError("model must be a MaskedForwardEngine (score_masks/predict), got %r" % type(engine))
+        x = torch.as_tensor(input_chw)
+        if x.dim() == 4:
+            x = x[0]
+        if x.dtype != torch.float32 or tuple(x.shape) != (3, IMG, IMG):
+            raise ValueError("input must be float32[1,3,224,224] (normalised), got %s%s" % (x.dtype, tuple(x.shape)))
+        self.engine = engine
+        self.input = x.contiguous()
+        self.label = _as_int(target)
+        if segments is None:
+            seg_fn = segmenter or _CONFIG["segmenter"] or default_segmenter
+            segments = seg_fn(img_show_u8(self.input.numpy()))
+        self.seg_rank, self.num_segments = rank_segments(segments)
+        self.window = masks.window_size(self.num_segments)
+        self.upper_bound = masks.bo_upper_bound(self.num_segments)
+        self._table = None
+        self.base_pred = None
+        if check_base:
+            self.base_pred, _ = engine.predict(self.input)
+            if self.base_pred != self.label:
+                raise BasePredictionWrong("unmasked prediction %d != label %d" % (self.base_pred, self.label))
+
+    def score_windows(self, first_indices):
+        onoff = masks.windows_onoff(self.num_segments, first_indices)
+        _o, score, pred = self.engine.score_masks(self.input, self.seg_rank, onoff, self.label)
+        return onoff, score, pred
+
+    def table(self):
+        """Scores of every window start 0..S (one batched pass; the BO domain is [0, int(0.6*S)])."""
+        if self._table is None:
+            idx = list(range(0, self.num_segments + 1))
+            _o, score, pred = self.score_windows(idx)
+            self._table = (score, pred)
+        return self._table
+
+    def score(self, first_index):
+        f = int(first_index)
+        if 0 <= f <= self.num_segments:
+            score, pred = self.table()
+            return score[f], int(pred[f])
+        _o, score, pred = self.score_windows([f])
+        return score[0], int(pred[0])
+
+    def mask_u8(self, first_index):
+        """u8[224,224] in {0,255} (`mask*255`, bayesian_active_learning_imagenet.py:276)."""
+        return masks.expand_pixel_mask(self.seg_rank, masks.window_onoff(self.num_segments, first_index)) * np.uint8(255)
+
+
+def _pick(val_loader, eval_img_index):
+    count = 0
+    for item in val_loader:
+        count += 1
+        if count > eval_img_index:
+            break
+        if count == eval_img_index:
+            return item
+    return None
+
+
+def _session(val_loader, model, eval_img_index):
+    key = (id(model), id(val_loader), int(eval_img_index))
+    s = _SESSIONS.get(key)
+    if s is None:
+        item = _pick(val_loader, eval_img_index)
+        if item is None:
+            return None
+        s = SaliencySession(model, item[0], item[1])
+        _SESSIONS[key] = s
+    _LAST["session"] = s
+    return s
+
+
+def _write_png(path, mask_u8):
+    from PIL import Image
+    Image.fromarray(mask_u8, mode="L").save(path)
+
+
+def validate_nueral_network(val_loader, model, criterion, bo_iter, firstIndex):
+    """-> np.float32 softmax probability of the true class for the window starting at firstIndex
+    (bayesian_active_learning_imagenet.py:116-218).  Raises BasePredictionWrong where the
+    reference raises a bare Exception (:219-221).  With configure(mask_dir=...) also writes
+    mask_{bo_iter}_{0|1}.png (:210,215)."""
+    s = _session(val_loader, model, _CONFIG["eval_img_index"])
+    if s is None:
+        return None
+    score, pred = s.score(int(firstIndex))
+    if _CONFIG["mask_dir"]:
+        os.makedirs(_CONFIG["mask_dir"], exist_ok=True)
+        _write_png(os.path.join(_CONFIG["mask_dir"], "mask_{}_{}.png".format(bo_iter, 1 if pred == s.label else 0)),
+                   s.mask_u8(int(firstIndex)))
+    return np.float32(score)
+
+
+def sample_loss(params, val_loader, model, criterion):
+    """The BO objective, bayesian_active_learning_imagenet.py:278-298:
+    firstIndex = int(params[0]); returns the class probability score."""
+    firstIndex = int(params[0])
+    bo_iter = params[0]
+    return validate_nueral_network(val_loader, model, criterion, bo_iter, firstIndex)
+
+
+def superpixel_mask(firstIndex, session=None):
+    """u8[224,224] in {0,255} for the window at firstIndex
+    (bayesian_active_learning_imagenet.py:224-276; called by BayesianOptimization.py:204-205).
+    Uses the most recent session instead of re-reading the dataset."""
+    s = session or _LAST["session"]
+    if s is None:
+        raise RuntimeError("superpixel_mask needs a session: call sample_loss/validate_nueral_network first")
+    return s.mask_u8(int(firstIndex))
+
+
+def _generator_pass(val_loader, model, eval_img_index, num_mask_samples, rng):
+    s = _session(val_loader, model, eval_img_index)
+    if s is None:
+        return None
+    rng = rng or (random.Random(_CONFIG["seed"]) if _CONFIG["seed"] is not None else random)
+    firsts = masks.draw_first_indices(s.num_segments, num_mask_samples, rng)
+    table_score, table_pred = s.table()
+    pred = np.array([table_pred[f] for f in firsts], dtype=np.int64)
+    correct = pred == s.label
+    return s, firsts, correct
+
+
+def validate(val_loader, model, criterion, eval_img_index, num_mask_samples=None, rng=None):
+    """-> correct_pred_count (int), generate_gp_training_data_imagenet.py:152-273: draws
+    num_mask_samples random windows, labels each 1 if the masked prediction is still the target.
+    With configure(mask_dir=...) writes mask_{i}_{label}.png (:260,265).  Returns 0 after printing
+    "wrong prediction" when the unmasked prediction is wrong (:269-273)."""
+    n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
+    try:
+        out = _generator_pass(val_loader, model, eval_img_index, n, rng)
+    except BasePredictionWrong:
+        print("wrong prediction")
+        return 0
+    if out is None:
+        return 0
+    s, firsts, correct = out
+    if _CONFIG["mask_dir"]:
+        os.makedirs(_CONFIG["mask_dir"], exist_ok=True)
+        for i, (f, ok) in enumerate(zip(firsts, correct)):
+            _write_png(os.path.join(_CONFIG["mask_dir"], "mask_{}_{}.png".format(i, int(ok))), s.mask_u8(f))
+    return int(correct.sum())
+
+
+def validate_summed(val_loader, model, criterion, eval_img_index, num_mask_samples=None, rng=None):
+    """-> summed_superpixel_labels f64[224,224]: sum over correct masks of the pixel mask
+    (gp_superpixel_data_imagenet.py:322-323,350; equals gp_regression.py:82-94's
+    y[p] = sum_i label_i*mask_i[p]).  The JET heat-map picture is plotting and not produced."""
+    n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
+    try:
+        out = _generator_pass(val_loader, model, eval_img_index, n, rng)
+    except BasePredictionWrong:
+        print("wrong prediction")
+        return np.zeros((IMG, IMG), dtype=np.float64)
+    if out is None:
+        return np.zeros((IMG, IMG), dtype=np.float64)
+    s, firsts, correct = out
+    onoff = masks.windows_onoff(s.num_segments, firsts)
+    per_segment = (onoff * correct[:, None].astype(np.uint8)).sum(0).astype(np.float64)
+    return per_segment[s.seg_rank]
+
+
+def score_masks(model, image, segments, onoff, label):
+    """The batched surface: -> (onoff u8[M,S], score f32[M], pred i32[M])."""
+    return model.score_masks(image, segments, onoff, label)

@@ -1,0 +1,604 @@
+// mpx_api.hip -- C-ABI (include/mpx.h) + host-side engine: topology, weight packing, workspace,
+// launch sequencing.  Compiled for gfx950 only:  hipcc --offload-arch=gfx950 -shared -fPIC.
+#include "../../include/mpx.h"
+#include "mpx_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <initializer_list>
+#include <new>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mpx;
+
+namespace {
+
+constexpr int kActBufs = 4;
+constexpr int kStemK = 7;
+constexpr int kProfilePairs = 4096;
+constexpr size_t kActElemsPerImage = 112 * 112 * 64;   // largest activation (stem output, = 56*56*256)
+
+enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3 };
+enum Buf { BUF_INPUT = -1, BUF_POOL = -2, BUF_NONE = -3 };
+
+struct ConvLayer {
+    mpx_conv_desc d;
+    half_t* w_hi = nullptr;
+    half_t* w_lo = nullptr;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    bool loaded = false;
+    bool is_fc = false;
+    bool is_stem = false;
+};
+
+struct Op {
+    int kind;
+    int conv;       // layer index for OP_CONV
+    int in, out, res;
+    int hin, c;     // pools
+};
+
+struct ProfRec {
+    hipEvent_t t0, t1;
+    int kind;
+    int conv;
+};
+
+}  // namespace
+
+struct mpx_engine {
+    int arch = 0, max_batch = 0, device = 0;
+    bool bottleneck = false;
+    int feat = 0;
+    std::vector<ConvLayer> convs;
+    std::vector<Op> ops;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    half_t* in_hi = nullptr;
+    half_t* in_lo = nullptr;
+    half_t* act_hi[kActBufs] = {};
+    half_t* act_lo[kActBufs] = {};
+    half_t* pool_hi = nullptr;
+    half_t* pool_lo = nullptr;
+    float* logits = nullptr;
+    half_t* zero_page = nullptr;
+    std::string err;
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pool;
+    int prof_used = 0;
+    hipStream_t prof_stream = nullptr;
+};
+
+namespace {
+
+int fail(mpx_engine* h, int code, const char* fmt, ...) {
+    if (h) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        h->err = buf;
+    }
+    return code;
+}
+
+#define MPX_HIP(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((h), (int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void set_name(char* dst, const std::string& s) {
+    std::snprintf(dst, 48, "%s", s.c_str());
+}
+
+// torchvision ResNet topology (models/resnet.py, un-vendored): conv list and op list.
+int build_topology(mpx_engine* h) {
+    int depths[4];
+    switch (h->arch) {
+        case 18: depths[0] = 2; depths[1] = 2; depths[2] = 2; depths[3] = 2; h->bottleneck = false; break;
+        case 34: depths[0] = 3; depths[1] = 4; depths[2] = 6; depths[3] = 3; h->bottleneck = false; break;
+        case 50: depths[0] = 3; depths[1] = 4; depths[2] = 6; depths[3] = 3; h->bottleneck = true; break;
+        case 101: depths[0] = 3; depths[1] = 4; depths[2] = 23; depths[3] = 3; h->bottleneck = true; break;
+        case 152: depths[0] = 3; depths[1] = 8; depths[2] = 36; depths[3] = 3; h->bottleneck = true; break;
+        default: return MPX_E_ARG;
+    }
+    const int exp = h->bottleneck ? 4 : 1;
+    auto add_conv = [&](const std::string& name, const std::string& bn, int cin, int cout, int k, int stride,
+                        int pad, int hin, int relu, int residual) {
+        ConvLayer L;
+        std::memset(&L.d, 0, sizeof L.d);
+        set_name(L.d.name, name);
+        set_name(L.d.bn_name, bn);
+        L.d.cin = cin; L.d.cout = cout; L.d.ksize = k; L.d.stride = stride; L.d.pad = pad;
+        L.d.hin = hin; L.d.hout = (hin + 2 * pad - k) / stride + 1;
+        L.d.relu = relu; L.d.residual = residual;
+        L.is_stem = (cin == 3);
+        L.d.k_packed = L.is_stem ? kStemK * 32 : k * k * cin;
+        L.d.cout_pad = (int)round_up(cout, 128);
+        h->convs.push_back(L);
+        return (int)h->convs.size() - 1;
+    };
+    auto add_op = [&](int kind, int conv, int in, int out, int res, int hin, int c) {
+        Op o{kind, conv, in, out, res, hin, c};
+        h->ops.push_back(o);
+    };
+    auto pick = [&](std::initializer_list<int> busy) {
+        for (int b = 0; b < kActBufs; ++b) {
+            bool used = false;
+            for (int u : busy) used |= (u == b);
+            if (!used) return b;
+        }
+        return -100;
+    };
+
+    int c = add_conv("conv1", "bn1", 3, 64, 7, 2, 3, 224, 1, 0);
+    add_op(OP_CONV, c, BUF_INPUT, 0, BUF_NONE, 0, 0);
+    add_op(OP_MAXPOOL, -1, 0, 1, BUF_NONE, 112, 64);
+    int X = 1, cin = 64, hcur = 56;
+    const int widths[4] = {64, 128, 256, 512};
+    for (int s = 0; s < 4; ++s) {
+        const int w = widths[s];
+        for (int b = 0; b < depths[s]; ++b) {
+            const int stride = (b == 0 && s > 0) ? 2 : 1;
+            const std::string p = "layer" + std::to_string(s + 1) + "." + std::to_string(b) + ".";
+            const bool ds = (b == 0) && (stride != 1 || cin != w * exp);
+            const int hout = hcur / stride;
+            if (!h->bottleneck) {
+                const int T1 = pick({X});
+                c = add_conv(p + "conv1", p + "bn1", cin, w, 3, stride, 1, hcur, 1, 0);
+                add_op(OP_CONV, c, X, T1, BUF_NONE, 0, 0);
+                int res = X, T2 = -100;
+                if (ds) {
+                    T2 = pick({X, T1});
+                    c = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
+                    add_op(OP_CONV, c, X, T2, BUF_NONE, 0, 0);
+                    res = T2;
+                }
+                const int O = pick({X, T1, T2});
+                c = add_conv(p + "conv2", p + "bn2", w, w, 3, 1, 1, hout, 1, 1);
+                add_op(OP_CONV, c, T1, O, res, 0, 0);
+                X = O;
+            } else {
+                const int T1 = pick({X});
+                c = add_conv(p + "conv1", p + "bn1", cin, w, 1, 1, 0, hcur, 1, 0);
+                add_op(OP_CONV, c, X, T1, BUF_NONE, 0, 0);
+                const int T2 = pick({X, T1});
+                c = add_conv(p + "conv2", p + "bn2", w, w, 3, stride, 1, hcur, 1, 0);
+                add_op(OP_CONV, c, T1, T2, BUF_NONE, 0, 0);
+                int res = X;
+                if (ds) {
+                    const int T3 = pick({X, T1, T2});
+                    c = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
+                    add_op(OP_CONV, c, X, T3, BUF_NONE, 0, 0);
+                    res = T3;
+                }
+                c = add_conv(p + "conv3", p + "bn3", w, w * exp, 1, 1, 0, hout, 1, 1);
+                add_op(OP_CONV, c, T2, T1, res, 0, 0);   // T1 is dead after conv2
+                X = T1;
+            }
+            cin = w * exp;
+            hcur = hout;
+        }
+    }
+    h->feat = cin;
+    add_op(OP_AVGPOOL, -1, X, BUF_POOL, BUF_NONE, hcur, cin);
+    c = add_conv("fc", "", cin, MPX_NUM_CLASSES, 1, 1, 0, 1, 0, 0);
+    h->convs[c].is_fc = true;
+    add_op(OP_CONV, c, BUF_POOL, BUF_NONE, BUF_NONE, 0, 0);
+    add_op(OP_HEAD, -1, BUF_NONE, BUF_NONE, BUF_NONE, 0, 0);
+    return 0;
+}
+
+uint16_t half_bits(half_t v) {
+    uint16_t u;
+    std::memcpy(&u, &v, 2);
+    return u;
+}
+
+hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+struct ProfScope {
+    mpx_engine* h;
+    hipStream_t st;
+    ProfRec* rec = nullptr;
+    ProfScope(mpx_engine* h_, hipStream_t st_, int kind, int conv) : h(h_), st(st_) {
+        if (h->prof_on && h->prof_used < (int)h->prof_pool.size()) {
+            rec = &h->prof_pool[h->prof_used++];
+            rec->kind = kind;
+            rec->conv = conv;
+            h->prof_stream = st;
+            (void)hipEventRecord(rec->t0, st);
+        }
+    }
+    ~ProfScope() {
+        if (rec) (void)hipEventRecord(rec->t1, st);
+    }
+};
+
+template <int TC, int TP>
+int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = cout_pad / TC;
+    const int n_tiles_p = (p.M + TP - 1) / TP;
+    const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
+    if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    const size_t lds = 2 * (size_t)(TC + TP) * 128;
+    hipLaunchKernelGGL((conv_f16x3_kernel<TC, TP>), dim3((unsigned)nblocks), dim3(256), lds, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
+                const half_t* r_lo, half_t* y_hi, half_t* y_lo, float* y_f32, int B, hipStream_t st) {
+    const ConvLayer& L = h->convs[i];
+    if (!L.loaded) return fail(h, MPX_E_STATE, "layer %d (%s) has no weights", i, L.d.name);
+    ConvParams p;
+    std::memset(&p, 0, sizeof p);
+    p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.scale = L.scale; p.shift = L.shift;
+    p.r_hi = r_hi; p.r_lo = r_lo; p.y_hi = y_hi; p.y_lo = y_lo; p.y_f32 = y_f32;
+    p.zero_page = h->zero_page;
+    p.cout = L.d.cout;
+    p.relu = L.d.relu;
+    p.ktot = L.d.k_packed;
+    if (L.is_stem) {
+        // padded NHWC4 staging: a (ky) tap is one 64-B run of 8 pixels x 4 channels, no bounds to check
+        p.x_hi = h->in_hi; p.x_lo = h->in_lo;
+        p.hin = MPX_IMG_PAD; p.win = MPX_IMG_PAD; p.pix_stride = 4;
+        p.kh = kStemK; p.kw = 1; p.stride = 2; p.pad = 0; p.k_per_tap = 32;
+    } else {
+        p.x_hi = in_hi; p.x_lo = in_lo;
+        p.hin = L.d.hin; p.win = L.d.hin; p.pix_stride = L.d.cin;
+        p.kh = L.d.ksize; p.kw = L.d.ksize; p.stride = L.d.stride; p.pad = L.d.pad; p.k_per_tap = L.d.cin;
+    }
+    p.ho = L.d.hout; p.wo = L.d.hout;
+    const long long M = (long long)B * p.ho * p.wo;
+    if (M > 0x7fffffffLL || (long long)B * p.hin * p.win > 0x7fffffffLL)
+        return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
+    p.M = (int)M;
+    ProfScope ps(h, st, OP_CONV, i);
+    if (L.d.cout >= 128) return launch_conv_tile<128, 128>(h, p, L.d.cout_pad, st);
+    return launch_conv_tile<64, 128>(h, p, L.d.cout_pad, st);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma, const float* beta,
+                          const float* mean, const float* var, float eps, uint16_t* w_hi, uint16_t* w_lo,
+                          float* scale, float* shift) {
+    if (!d || !w || !w_hi || !w_lo || !scale || !shift) return MPX_E_ARG;
+    const int cin = d->cin, cout = d->cout, k = d->ksize, K = d->k_packed;
+    const bool stem = (cin == 3);
+    if (stem ? (k != kStemK || K != kStemK * 32) : (K != k * k * cin || K % 32 != 0)) return MPX_E_ARG;
+    std::memset(w_hi, 0, (size_t)d->cout_pad * K * 2);
+    std::memset(w_lo, 0, (size_t)d->cout_pad * K * 2);
+    for (int co = 0; co < d->cout_pad; ++co) {
+        scale[co] = 0.f;
+        shift[co] = 0.f;
+    }
+    for (int co = 0; co < cout; ++co) {
+        const float* wc = w + (size_t)co * cin * k * k;
+        float mx = 0.f;
+        for (int j = 0; j < cin * k * k; ++j) mx = std::fmax(mx, std::fabs(wc[j]));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) {
+            int ex;
+            std::frexp(mx, &ex);          // mx = f * 2^ex, f in [0.5,1)  ->  mx*2^(10-ex) in [512,1024)
+            e = 10 - ex;
+        }
+        uint16_t* ph = w_hi + (size_t)co * K;
+        uint16_t* pl = w_lo + (size_t)co * K;
+        auto put = [&](int kk, float v) {
+            const float sv = std::ldexp(v, e);
+            const half_t hi = (half_t)sv;
+            const half_t lo = (half_t)(sv - (float)hi);
+            ph[kk] = half_bits(hi);
+            pl[kk] = half_bits(lo);
+        };
+        if (stem) {
+            for (int ky = 0; ky < k; ++ky)
+                for (int px = 0; px < k; ++px)
+                    for (int c = 0; c < 3; ++c) put(ky * 32 + px * 4 + c, wc[((size_t)c * k + ky) * k + px]);
+        } else {
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx)
+                    for (int ci = 0; ci < cin; ++ci)
+                        put((ky * k + kx) * cin + ci, wc[((size_t)ci * k + ky) * k + kx]);
+        }
+        double s = 1.0, t = 0.0;
+        if (gamma) {
+            s = (double)gamma[co] / std::sqrt((double)var[co] + (double)eps);
+            t = (double)beta[co] - (double)mean[co] * s;
+        } else if (beta) {
+            t = beta[co];
+        }
+        scale[co] = (float)std::ldexp(s, -e);
+        shift[co] = (float)t;
+    }
+    return 0;
+}
+
+int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
+    if (!out || max_batch <= 0) return MPX_E_ARG;
+    *out = nullptr;
+    mpx_engine* h = new (std::nothrow) mpx_engine();
+    if (!h) return MPX_E_NOMEM;
+    h->arch = arch_id; h->max_batch = max_batch; h->device = device;
+    int rc = build_topology(h);
+    if (rc) { delete h; return rc; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete h; return (int)e; }
+
+    // one arena: zero page | input planes | activation planes | pooled | logits | weights
+    const size_t in_plane = round_up((size_t)max_batch * MPX_IMG_PAD * MPX_IMG_PAD * 4 * 2 + 256, 256);
+    const size_t act_plane = round_up((size_t)max_batch * kActElemsPerImage * 2, 256);
+    const size_t pool_plane = round_up((size_t)max_batch * h->feat * 2, 256);
+    const size_t logit_bytes = round_up((size_t)max_batch * MPX_NUM_CLASSES * 4, 256);
+    size_t wbytes = 0;
+    for (const ConvLayer& L : h->convs)
+        wbytes += 2 * round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
+    const size_t total = 256 + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
+    e = hipMalloc((void**)&h->arena, total);
+    if (e != hipSuccess) { delete h; return (int)e; }
+    h->arena_bytes = total;
+    char* cur = h->arena;
+    auto take = [&](size_t n) { char* r = cur; cur += n; return r; };
+    h->zero_page = (half_t*)take(256);
+    h->in_hi = (half_t*)take(in_plane);
+    h->in_lo = (half_t*)take(in_plane);
+    for (int b = 0; b < kActBufs; ++b) {
+        h->act_hi[b] = (half_t*)take(act_plane);
+        h->act_lo[b] = (half_t*)take(act_plane);
+    }
+    h->pool_hi = (half_t*)take(pool_plane);
+    h->pool_lo = (half_t*)take(pool_plane);
+    h->logits = (float*)take(logit_bytes);
+    for (ConvLayer& L : h->convs) {
+        const size_t wb = round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256);
+        const size_t sb = round_up((size_t)L.d.cout_pad * 4, 256);
+        L.w_hi = (half_t*)take(wb);
+        L.w_lo = (half_t*)take(wb);
+        L.scale = (float*)take(sb);
+        L.shift = (float*)take(sb);
+    }
+    // zero page and the never-written borders of the input staging must be zero
+    e = hipMemset(h->arena, 0, 256 + 2 * in_plane);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
+    *out = h;
+    return 0;
+}
+
+int mpx_destroy(mpx_engine* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    for (ProfRec& r : h->prof_pool) {
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
+    }
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+    return 0;
+}
+
+const char* mpx_last_error(const mpx_engine* h) { return h ? h->err.c_str() : "null engine"; }
+int mpx_max_batch(const mpx_engine* h) { return h ? h->max_batch : MPX_E_ARG; }
+size_t mpx_workspace_bytes(const mpx_engine* h) { return h ? h->arena_bytes : 0; }
+int mpx_num_convs(const mpx_engine* h) { return h ? (int)h->convs.size() : MPX_E_ARG; }
+
+int mpx_conv_info(const mpx_engine* h, int i, mpx_conv_desc* out) {
+    if (!h || !out || i < 0 || i >= (int)h->convs.size()) return MPX_E_ARG;
+    *out = h->convs[i].d;
+    return 0;
+}
+
+int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamma, const float* beta,
+                         const float* mean, const float* var, float eps) {
+    if (!h) return MPX_E_ARG;
+    if (i < 0 || i >= (int)h->convs.size() || !w) return fail(h, MPX_E_ARG, "set_conv_weights: bad layer index or null weight");
+    ConvLayer& L = h->convs[i];
+    if (!L.is_fc && (!gamma || !beta || !mean || !var)) return fail(h, MPX_E_ARG, "set_conv_weights: BatchNorm tensors missing for %s", L.d.name);
+    const size_t n = (size_t)L.d.cout_pad * L.d.k_packed;
+    std::vector<uint16_t> hi(n), lo(n);
+    std::vector<float> sc(L.d.cout_pad), sh(L.d.cout_pad);
+    int rc = mpx_pack_conv_weights(&L.d, w, L.is_fc ? nullptr : gamma, beta, mean, var, eps, hi.data(), lo.data(), sc.data(), sh.data());
+    if (rc) return fail(h, rc, "pack failed for %s", L.d.name);
+    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_HIP(h, hipMemcpy(L.w_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.w_lo, lo.data(), n * 2, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    L.loaded = true;
+    return 0;
+}
+
+int mpx_weights_complete(const mpx_engine* h) {
+    if (!h) return MPX_E_ARG;
+    for (const ConvLayer& L : h->convs)
+        if (!L.loaded) return 0;
+    return 1;
+}
+
+int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const float* img_f32_chw, const int32_t* seg,
+                             const uint8_t* onoff, int M, int S, const float mean[3], const float std[3], int slot0,
+                             float* out_f32_nchw, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if ((img_u8_hwc == nullptr) == (img_f32_chw == nullptr))
+        return fail(h, MPX_E_ARG, "mask_apply_normalize: exactly one of img_u8_hwc / img_f32_chw must be given");
+    if (!seg || !onoff || M <= 0 || S <= 0) return fail(h, MPX_E_ARG, "mask_apply_normalize: null input or empty M/S");
+    if (img_u8_hwc && (!mean || !std)) return fail(h, MPX_E_ARG, "mask_apply_normalize: mean/std required for u8 input");
+    if (slot0 < 0 || slot0 + M > h->max_batch) return fail(h, MPX_E_STATE, "mask_apply_normalize: slots [%d,%d) exceed max_batch %d", slot0, slot0 + M, h->max_batch);
+    const size_t lds = round_up((size_t)K0_MT * S, 16);
+    if (lds > 64 * 1024) return fail(h, MPX_E_ARG, "mask_apply_normalize: S=%d too large (max %d)", S, 64 * 1024 / K0_MT);
+    MaskParams p;
+    std::memset(&p, 0, sizeof p);
+    p.img_u8 = img_u8_hwc; p.img_f32 = img_f32_chw; p.seg = seg; p.onoff = onoff;
+    p.out_hi = h->in_hi; p.out_lo = h->in_lo; p.out_f32 = out_f32_nchw;
+    for (int c = 0; c < 3; ++c) {
+        p.mean[c] = mean ? mean[c] : 0.f;
+        p.std[c] = std ? std[c] : 1.f;
+    }
+    p.M = M; p.S = S; p.slot0 = slot0;
+    p.size = MPX_IMG; p.pad_size = MPX_IMG_PAD; p.border = 3;
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 1, -1);
+    dim3 grid((MPX_IMG * MPX_IMG + 255) / 256, (M + K0_MT - 1) / K0_MT);
+    hipLaunchKernelGGL(mask_apply_normalize_kernel, grid, dim3(256), lds, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* res_hi, const void* res_lo,
+                    void* out_hi, void* out_lo, float* out_f32, int B, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (i < 0 || i >= (int)h->convs.size() || B <= 0) return fail(h, MPX_E_ARG, "conv_bn_act: bad layer index or batch");
+    const ConvLayer& L = h->convs[i];
+    if (L.is_stem) {
+        if (in_hi || in_lo) return fail(h, MPX_E_ARG, "conv_bn_act: layer 0 reads the engine input staging; pass NULL inputs");
+        if (B > h->max_batch) return fail(h, MPX_E_STATE, "conv_bn_act: B > max_batch");
+    } else if (!in_hi || !in_lo) {
+        return fail(h, MPX_E_ARG, "conv_bn_act: null input planes");
+    }
+    if ((res_hi == nullptr) != (res_lo == nullptr)) return fail(h, MPX_E_ARG, "conv_bn_act: residual planes must come in pairs");
+    if (L.is_fc ? (out_f32 == nullptr) : (out_f32 != nullptr || !out_hi || !out_lo))
+        return fail(h, MPX_E_ARG, "conv_bn_act: fc writes out_f32, every other layer writes out_hi/out_lo");
+    MPX_HIP(h, hipSetDevice(h->device));
+    return launch_conv(h, i, (const half_t*)in_hi, (const half_t*)in_lo, (const half_t*)res_hi, (const half_t*)res_lo,
+                       (half_t*)out_hi, (half_t*)out_lo, out_f32, B, as_stream(stream));
+}
+
+int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B, int hin,
+                     int c, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hin <= 0 || (hin & 1) || c <= 0 || (c & 7))
+        return fail(h, MPX_E_ARG, "maxpool3x3s2: bad arguments (hin even, c multiple of 8)");
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 2, -1);
+    const size_t total = (size_t)B * (hin / 2) * (hin / 2) * (c / 8);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, st, (const half_t*)in_hi, (const half_t*)in_lo,
+                       (half_t*)out_hi, (half_t*)out_lo, B, hin, c);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_global_avgpool(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B, int hw,
+                       int c, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hw <= 0 || c <= 0 || (c & 7))
+        return fail(h, MPX_E_ARG, "global_avgpool: bad arguments (c multiple of 8)");
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 2, -1);
+    const int total = B * (c / 8);
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const half_t*)in_hi,
+                       (const half_t*)in_lo, (half_t*)out_hi, (half_t*)out_lo, B, hw, c);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* label, float* score, int32_t* pred,
+                            int B, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!logits || !label || !score || !pred || B <= 0) return fail(h, MPX_E_ARG, "head_softmax_gather: null pointer or empty batch");
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 3, -1);
+    hipLaunchKernelGGL(head_softmax_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, label, score, pred, B,
+                       MPX_NUM_CLASSES);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred, float* logits_out, int B,
+                void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!label || !score || !pred || B <= 0) return fail(h, MPX_E_ARG, "forward: null pointer or empty batch");
+    if (B > h->max_batch) return fail(h, MPX_E_STATE, "forward: B=%d exceeds max_batch=%d", B, h->max_batch);
+    if (mpx_weights_complete(h) != 1) return fail(h, MPX_E_STATE, "forward: weights not loaded for every layer");
+    float* logits = logits_out ? logits_out : h->logits;
+    auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b >= 0 ? h->act_hi[b] : nullptr); };
+    auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
+    int rc = 0;
+    for (const Op& o : h->ops) {
+        switch (o.kind) {
+            case OP_CONV:
+                if (h->convs[o.conv].is_fc)
+                    rc = mpx_conv_bn_act(h, o.conv, hi(o.in), lo(o.in), nullptr, nullptr, nullptr, nullptr, logits, B, stream);
+                else
+                    rc = mpx_conv_bn_act(h, o.conv, hi(o.in), lo(o.in), hi(o.res), lo(o.res), hi(o.out), lo(o.out), nullptr, B, stream);
+                break;
+            case OP_MAXPOOL: rc = mpx_maxpool3x3s2(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c, stream); break;
+            case OP_AVGPOOL: rc = mpx_global_avgpool(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin * o.hin, o.c, stream); break;
+            case OP_HEAD: rc = mpx_head_softmax_gather(h, logits, label, score, pred, B, stream); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mpx_input_planes(const mpx_engine* h, void** hi, void** lo) {
+    if (!h || !hi || !lo) return MPX_E_ARG;
+    *hi = h->in_hi;
+    *lo = h->in_lo;
+    return 0;
+}
+
+int mpx_profile_enable(mpx_engine* h, int on) {
+    if (!h) return MPX_E_ARG;
+    if (on && h->prof_pool.empty()) {
+        MPX_HIP(h, hipSetDevice(h->device));
+        h->prof_pool.resize(kProfilePairs);
+        for (ProfRec& r : h->prof_pool) {
+            MPX_HIP(h, hipEventCreate(&r.t0));
+            MPX_HIP(h, hipEventCreate(&r.t1));
+        }
+    }
+    h->prof_on = on != 0;
+    return 0;
+}
+
+int mpx_profile_collect(mpx_engine* h, double ms_by_kind[4], long long launches_by_kind[4], double* per_conv_ms) {
+    if (!h || !ms_by_kind || !launches_by_kind) return MPX_E_ARG;
+    if (h->prof_used == 0) return 0;
+    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_HIP(h, hipEventSynchronize(h->prof_pool[h->prof_used - 1].t1));
+    for (int i = 0; i < h->prof_used; ++i) {
+        ProfRec& r = h->prof_pool[i];
+        float ms = 0.f;
+        MPX_HIP(h, hipEventElapsedTime(&ms, r.t0, r.t1));
+        ms_by_kind[r.kind] += ms;
+        launches_by_kind[r.kind] += 1;
+        if (per_conv_ms && r.kind == OP_CONV && r.conv >= 0) per_conv_ms[r.conv] += ms;
+    }
+    h->prof_used = 0;
+    return 0;
+}
+
+double mpx_flops_per_forward(const mpx_engine* h) {
+    if (!h) return 0.0;
+    double macs = 0.0;
+    for (const ConvLayer& L : h->convs)
+        macs += (double)L.d.hout * L.d.hout * L.d.cout * L.d.cin * L.d.ksize * L.d.ksize;
+    return 2.0 * macs;
+}
+
+}  // extern "C"

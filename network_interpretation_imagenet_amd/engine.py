@@ -1,0 +1,258 @@
+"""Host side of the masked-perturbation scorer: PyTorch-ROCm provides device memory and streams,
+every computation is a hand-written HIP kernel behind the C-ABI of include/mpx.h.
+
+Replaces the inner loop of the reference's three hot-path scripts
+(generate_gp_training_data_imagenet.py:221-266, gp_superpixel_data_imagenet.py:276-334,
+bayesian_active_learning_imagenet.py:170-218): mask build, `input * mask`, per-mask H2D copy,
+batch-1 forward, per-mask D2H sync.  Here M masks of one image are staged and scored in one
+batched launch sequence and only the M scores come back.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MpxError, IMG, NUM_CLASSES
+
+# transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+# generate_gp_training_data_imagenet.py:590-591
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+BN_EPS = 1e-5   # torchvision BatchNorm2d default
+
+ARCH_IDS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnet101": 101, "resnet152": 152}
+
+
+class BasePredictionWrong(Exception):
+    """The unmasked prediction differs from the label; the reference only defines the scorer when
+    it is correct (generate_gp_training_data_imagenet.py:215,269-273;
+    bayesian_active_learning_imagenet.py:167,219-221)."""
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def rank_segments(segments):
+    """Arbitrary integer label map -> (i32[224,224] ranks in np.unique(segments) order, S).
+    The reference indexes superpixels through np.unique(segments)
+    (generate_gp_training_data_imagenet.py:223,230)."""
+    seg = np.asarray(segments)
+    if seg.shape != (IMG, IMG):
+        raise ValueError("segments must be [%d,%d], got %s" % (IMG, IMG, seg.shape))
+    if not np.issubdtype(seg.dtype, np.integer):
+        raise ValueError("segments must be an integer label map, got %s" % seg.dtype)
+    uniq, inv = np.unique(seg, return_inverse=True)
+    return inv.reshape(IMG, IMG).astype(np.int32), int(len(uniq))
+
+
+class MaskedForwardEngine:
+    """One engine per process per GPU (one RCCL rank).  `arch` is the reference's `-a/--arch`."""
+
+    def __init__(self, arch="resnet101", max_batch=512, device=None):
+        if arch not in ARCH_IDS:
+            raise ValueError("unsupported arch %r (torchvision ResNets only: %s)" % (arch, sorted(ARCH_IDS)))
+        if not torch.cuda.is_available():
+            raise MpxError("no MI355X visible: the scorer has no CPU path")
+        self._lib = _lib.load()
+        self.arch = arch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.max_batch = int(max_batch)
+        h = C.c_void_p()
+        rc = self._lib.mpx_create(ARCH_IDS[arch], self.max_batch, self.device.index, C.byref(h))
+        if rc != 0:
+            raise MpxError("mpx_create(%s, max_batch=%d) failed rc=%d" % (arch, max_batch, rc))
+        self._h = h
+        self.layers = []
+        for i in range(self._lib.mpx_num_convs(h)):
+            d = _lib.ConvDesc()
+            _lib.check(h, self._lib.mpx_conv_info(h, i, C.byref(d)), "mpx_conv_info")
+            self.layers.append(d)
+        self.flops_per_forward = float(self._lib.mpx_flops_per_forward(h))
+        self._mean, self._std = _f3(MEAN), _f3(STD)
+
+    # ---- life cycle ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mpx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self):
+        """nn.Module.eval() of the reference (generate_gp_training_data_imagenet.py:159): the engine
+        only has the inference mode (BatchNorm running statistics)."""
+        return self
+
+    def cuda(self):
+        return self
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.mpx_workspace_bytes(self._h))
+
+    # ---- weights ----
+    def load_state_dict(self, sd, eps=BN_EPS):
+        """`sd`: torchvision ResNet state_dict (key names as `models.<arch>().state_dict()`), e.g.
+        torch.load(local_path, weights_only=True).  `module.` prefixes (DataParallel) are accepted."""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+        def get(key, shape):
+            if key not in sd:
+                raise KeyError("state_dict lacks %r" % key)
+            t = sd[key].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError("%s has shape %s, expected %s" % (key, tuple(t.shape), shape))
+            return t
+
+        for i, d in enumerate(self.layers):
+            name, bn = d.name.decode(), d.bn_name.decode()
+            if name == "fc":
+                w = get("fc.weight", (NUM_CLASSES, d.cin))
+                b = get("fc.bias", (NUM_CLASSES,))
+                args = (_ptr(w), None, _ptr(b), None, None)
+            else:
+                w = get(name + ".weight", (d.cout, d.cin, d.ksize, d.ksize))
+                g = get(bn + ".weight", (d.cout,))
+                b = get(bn + ".bias", (d.cout,))
+                m = get(bn + ".running_mean", (d.cout,))
+                v = get(bn + ".running_var", (d.cout,))
+                args = (_ptr(w), _ptr(g), _ptr(b), _ptr(m), _ptr(v))
+            _lib.check(self._h, self._lib.mpx_set_conv_weights(self._h, i, *args, float(eps)),
+                       "mpx_set_conv_weights(%s)" % name)
+        return self
+
+    # ---- kernels ----
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def stage_masks(self, image, seg, onoff, slot0=0, out_f32=None):
+        """K0.  image: device u8[224,224,3] (raw) or f32[3,224,224] (normalised); seg: device
+        i32[224,224] ranks; onoff: device u8[M,S].  Fills input slots [slot0, slot0+M)."""
+        for name, t in (("image", image), ("seg", seg), ("onoff", onoff)):
+            if t.device != self.device or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous tensor on %s" % (name, self.device))
+        if seg.dtype != torch.int32 or tuple(seg.shape) != (IMG, IMG):
+            raise ValueError("seg must be int32[%d,%d]" % (IMG, IMG))
+        if onoff.dtype != torch.uint8 or onoff.dim() != 2:
+            raise ValueError("onoff must be uint8[M,S]")
+        m, s = onoff.shape
+        if image.dtype == torch.uint8 and tuple(image.shape) == (IMG, IMG, 3):
+            u8, f32 = _ptr(image), None
+        elif image.dtype == torch.float32 and tuple(image.shape) == (3, IMG, IMG):
+            u8, f32 = None, _ptr(image)
+        else:
+            raise ValueError("image must be uint8[224,224,3] or float32[3,224,224], got %s%s"
+                             % (image.dtype, tuple(image.shape)))
+        if out_f32 is not None and (out_f32.dtype != torch.float32 or tuple(out_f32.shape) != (m, 3, IMG, IMG)
+                                    or not out_f32.is_contiguous()):
+            raise ValueError("out_f32 must be contiguous float32[M,3,224,224]")
+        _lib.check(self._h, self._lib.mpx_mask_apply_normalize(
+            self._h, u8, f32, _ptr(seg), _ptr(onoff), int(m), int(s), self._mean, self._std,
+            int(slot0), _ptr(out_f32), self._stream()), "mpx_mask_apply_normalize")
+
+    def forward(self, batch, labels, want_logits=False):
+        """Whole network over the staged slots [0,batch).  labels: device i32[batch].
+        returns (score f32[batch], pred i32[batch][, logits f32[batch,1000]]) on the device."""
+        if labels.dtype != torch.int32 or labels.device != self.device or labels.numel() != batch:
+            raise ValueError("labels must be int32[%d] on %s" % (batch, self.device))
+        score = torch.empty(batch, dtype=torch.float32, device=self.device)
+        pred = torch.empty(batch, dtype=torch.int32, device=self.device)
+        logits = torch.empty(batch, NUM_CLASSES, dtype=torch.float32, device=self.device) if want_logits else None
+        _lib.check(self._h, self._lib.mpx_forward(self._h, _ptr(labels), _ptr(score), _ptr(pred), _ptr(logits),
+                                                  int(batch), self._stream()), "mpx_forward")
+        return (score, pred, logits) if want_logits else (score, pred)
+
+    def input_planes(self, n=None):
+        """Zero-copy fp16 views [n,230,230,4] of the engine-owned padded NHWC4 input staging planes
+        (hi, lo).  For tests and diagnostics."""
+        n = self.max_batch if n is None else int(n)
+        hi, lo = C.c_void_p(), C.c_void_p()
+        _lib.check(self._h, self._lib.mpx_input_planes(self._h, C.byref(hi), C.byref(lo)), "mpx_input_planes")
+
+        class _View:
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n, _lib.IMG_PAD, _lib.IMG_PAD, 4),
+                                                 "typestr": "<f2", "version": 2}
+
+        return (torch.as_tensor(_View(hi.value), device=self.device),
+                torch.as_tensor(_View(lo.value), device=self.device))
+
+    # ---- the batched surface ----
+    def _image_to_device(self, image):
+        t = torch.as_tensor(image)
+        if t.dim() == 4 and t.shape[0] == 1:
+            t = t[0]
+        if t.dtype == torch.uint8:
+            if tuple(t.shape) != (IMG, IMG, 3):
+                raise ValueError("uint8 image must be [224,224,3] (HWC), got %s" % (tuple(t.shape),))
+        elif t.dtype == torch.float32:
+            if tuple(t.shape) != (3, IMG, IMG):
+                raise ValueError("float32 image must be [3,224,224] (normalised CHW), got %s" % (tuple(t.shape),))
+        else:
+            raise ValueError("image must be uint8 HWC or float32 CHW, got %s" % t.dtype)
+        return t.contiguous().to(self.device)
+
+    def score_masks(self, image, segments, onoff, label, return_logits=False):
+        """(image, segments, onoff u8[M,S], label) -> (onoff u8[M,S], score f32[M], pred i32[M]).
+        score[m] = softmax(model(normalised_image * mask_m))[label]
+        (bayesian_active_learning_imagenet.py:187-198); pred[m] == label is the generators' binary
+        label (generate_gp_training_data_imagenet.py:248,257)."""
+        seg_rank, s = rank_segments(segments)
+        onoff = np.ascontiguousarray(onoff)
+        if onoff.dtype != np.uint8 or onoff.ndim != 2 or onoff.shape[1] != s:
+            raise ValueError("onoff must be uint8[M,%d] (S = number of distinct segment labels), got %s%s"
+                             % (s, onoff.dtype, onoff.shape))
+        if not 0 <= int(label) < NUM_CLASSES:
+            raise ValueError("label %r outside [0,1000)" % (label,))
+        m = onoff.shape[0]
+        score = np.empty(m, dtype=np.float32)
+        pred = np.empty(m, dtype=np.int32)
+        logits = np.empty((m, NUM_CLASSES), dtype=np.float32) if return_logits else None
+        if m == 0:
+            return (onoff, score, pred, logits) if return_logits else (onoff, score, pred)
+        img_d = self._image_to_device(image)
+        seg_d = torch.from_numpy(seg_rank).to(self.device)
+        onoff_d = torch.from_numpy(onoff).to(self.device)
+        for s0 in range(0, m, self.max_batch):
+            b = min(self.max_batch, m - s0)
+            labels = torch.full((b,), int(label), dtype=torch.int32, device=self.device)
+            self.stage_masks(img_d, seg_d, onoff_d[s0:s0 + b], 0)
+            out = self.forward(b, labels, want_logits=return_logits)
+            score[s0:s0 + b] = out[0].cpu().numpy()
+            pred[s0:s0 + b] = out[1].cpu().numpy()
+            if return_logits:
+                logits[s0:s0 + b] = out[2].cpu().numpy()
+        return (onoff, score, pred, logits) if return_logits else (onoff, score, pred)
+
+    def predict(self, image):
+        """Unmasked forward: (argmax class, softmax f32[1000])
+        (generate_gp_training_data_imagenet.py:193,202)."""
+        seg = np.zeros((IMG, IMG), dtype=np.int32)
+        _o, _s, pred, logits = self.score_masks(image, seg, np.ones((1, 1), dtype=np.uint8), 0, return_logits=True)
+        z = logits[0].astype(np.float64)
+        p = np.exp(z - z.max())
+        return int(pred[0]), (p / p.sum()).astype(np.float32)
+
+    # ---- profiling ----
+    def profile(self, on=True):
+        _lib.check(self._h, self._lib.mpx_profile_enable(self._h, 1 if on else 0), "mpx_profile_enable")
+
+    def collect_profile(self):
+        """{'ms': {kind: ms}, 'launches': {kind: n}, 'per_conv_ms': [...]} accumulated since the last call."""
+        ms = (C.c_double * 4)()
+        n = (C.c_longlong * 4)()
+        per = (C.c_double * len(self.layers))()
+        _lib.check(self._h, self._lib.mpx_profile_collect(self._h, ms, n, per), "mpx_profile_collect")
+        kinds = ("conv", "mask_apply_normalize", "pool", "head")
+        return {"ms": dict(zip(kinds, list(ms))), "launches": dict(zip(kinds, list(n))),
+                "per_conv_ms": list(per)}

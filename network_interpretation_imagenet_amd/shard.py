@@ -1,0 +1,69 @@
+"""Mask-batch sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference has no distributed code (its --world-size/--dist-url flags are parsed and never
+read: generate_gp_training_data_imagenet.py:72-77,572).  Every (image, mask) pair is independent
+(:221-266), so the flattened work index w = img*M + m is cut into P contiguous blocks with no
+data-path collective; the only exchange is ONE all-gather of the per-mask scores (RCCL over xGMI
+when the backend is "nccl", gloo on CPU in the tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def block(total, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    return total * rank // world, total * (rank + 1) // world
+
+
+def image_ranges(lo, hi, masks_per_image):
+    """Split the flat range [lo,hi) into per-image pieces: [(img, m_lo, m_hi)], m_* within the image."""
+    out = []
+    w = lo
+    while w < hi:
+        img = w // masks_per_image
+        m_lo = w - img * masks_per_image
+        m_hi = min(masks_per_image, m_lo + (hi - w))
+        out.append((img, m_lo, m_hi))
+        w += m_hi - m_lo
+    return out
+
+
+def all_gather_blocks(local, total, group=None):
+    """local: 1-D tensor holding this rank's block (block(total, rank, world)) -> 1-D tensor of
+    length `total` on every rank.  One collective; uneven blocks are padded to the largest."""
+    if not dist.is_available() or not dist.is_initialized():
+        if local.numel() != total:
+            raise ValueError("single process must hold the whole range")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = block(total, rank, world)
+    if local.numel() != hi - lo:
+        raise ValueError("rank %d holds %d values, its block is %d" % (rank, local.numel(), hi - lo))
+    width = -(-total // world)
+    padded = torch.zeros(width, dtype=local.dtype, device=local.device)
+    padded[:hi - lo] = local
+    gathered = torch.empty(world * width, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    parts = []
+    for r in range(world):
+        rlo, rhi = block(total, r, world)
+        parts.append(gathered[r * width:r * width + (rhi - rlo)])
+    return torch.cat(parts)
+
+
+def score_sharded(score_image_fn, num_images, masks_per_image, device, group=None):
+    """score_image_fn(img, m_lo, m_hi) -> 1-D f32 tensor of m_hi-m_lo scores on `device`.
+    Runs this rank's block and returns all num_images*masks_per_image scores on every rank
+    (bit-identical to the 1-GPU result: same kernels, disjoint blocks)."""
+    total = num_images * masks_per_image
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = block(total, rank, world)
+    pieces = [score_image_fn(img, m_lo, m_hi) for img, m_lo, m_hi in image_ranges(lo, hi, masks_per_image)]
+    local = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.float32, device=device)
+    return all_gather_blocks(local, total, group)

@@ -1,0 +1,358 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Every check goes through the C-ABI of
+libmpx.so; the CPU oracle (oracle/) and torch CPU fp64 ops are the checkers.
+
+Tolerances: integer/bit work (K0 fp32 output, maxpool, argmax) is bit-exact; floating-point scores
+must be within 1e-4 of the reference-style CPU loop (BASELINE.json north_star) -- the split-fp16
+MFMA path is expected to land ~1e-6, so the tests also assert the tighter 2e-5.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from network_interpretation_imagenet_amd import _lib, masks, synth
+from network_interpretation_imagenet_amd.engine import MaskedForwardEngine, MpxError
+from oracle import resnet_ref, scorer
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-4        # north_star tolerance
+SCORE_TOL_TIGHT = 2e-5  # what split-fp16 should achieve
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def split(x):
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def merge(hi, lo):
+    return hi.float() + lo.float()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def eng18(mpx_lib, dev):
+    e = MaskedForwardEngine("resnet18", max_batch=64, device=0).load_state_dict(synth.make_state_dict("resnet18"))
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng101(mpx_lib, dev):
+    e = MaskedForwardEngine("resnet101", max_batch=32, device=0).load_state_dict(synth.make_state_dict("resnet101"))
+    yield e
+    e.close()
+
+
+def _input_planes(eng, n):
+    hi, lo = eng.input_planes(n)
+    return hi.clone(), lo.clone()
+
+
+# ------------------------------------------------------------------------------------------------
+# K0
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,seg_kind", [(5, "grid"), (37, "felz"), (64, "single")])
+def test_k0_u8_bit_exact(eng18, dev, golden_dir, m, seg_kind):
+    img = synth.make_images(2, kind="noise")[1]
+    if seg_kind == "grid":
+        seg = synth.grid_segments()
+    elif seg_kind == "felz":
+        seg = np.load(os.path.join(golden_dir, "segments_blobs.npz"))["segments"][0].astype(np.int32)
+    else:
+        seg = np.zeros((224, 224), dtype=np.int32)
+    s = int(seg.max()) + 1
+    onoff = synth.random_onoff(m, s, seed=m)
+    if seg_kind == "single":
+        onoff[:, 0] = np.arange(m) % 2
+    out = torch.empty(m, 3, 224, 224, dtype=torch.float32, device=dev)
+    eng18.stage_masks(torch.from_numpy(img).to(dev), torch.from_numpy(seg).to(dev), torch.from_numpy(onoff).to(dev), 0, out)
+    torch.cuda.synchronize()
+    x = scorer.to_tensor_normalize(img)
+    want = np.stack([scorer.apply_mask(x, scorer.onoff_mask_u8(seg, onoff[i])) for i in range(m)])
+    got = out.cpu().numpy()
+    assert (got.view(np.int32) == want.view(np.int32)).all()          # bit-exact, including -0.0
+    hi, lo = _input_planes(eng18, m)
+    staged = merge(hi, lo).cpu().numpy()
+    assert (staged[:, :3] == 0).all() and (staged[:, -3:] == 0).all() and (staged[:, :, :3] == 0).all() \
+        and (staged[:, :, -3:] == 0).all() and (staged[..., 3] == 0).all()      # border + 4th channel stay zero
+    inner = staged[:, 3:227, 3:227, :3].transpose(0, 3, 1, 2)
+    assert np.abs(inner - want).max() <= 2.0 ** -21 * np.abs(want).max()       # 22-bit split of the same values
+
+
+def test_k0_f32_input_and_slots(eng18, dev):
+    img = synth.make_images(1)[0]
+    x = scorer.to_tensor_normalize(img)
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(3, 196, seed=9)
+    out = torch.empty(3, 3, 224, 224, dtype=torch.float32, device=dev)
+    eng18.stage_masks(x.to(dev), torch.from_numpy(seg).to(dev), torch.from_numpy(onoff).to(dev), 7, out)
+    torch.cuda.synchronize()
+    want = np.stack([scorer.apply_mask(x, scorer.onoff_mask_u8(seg, onoff[i])) for i in range(3)])
+    assert (out.cpu().numpy().view(np.int32) == want.view(np.int32)).all()
+    hi, lo = _input_planes(eng18, 10)
+    got = merge(hi, lo)[7:10, 3:227, 3:227, :3].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - want).max() <= 2.0 ** -21 * np.abs(want).max()
+
+
+def test_k0_argument_errors(eng18, dev):
+    img = torch.zeros(224, 224, 3, dtype=torch.uint8, device=dev)
+    seg = torch.zeros(224, 224, dtype=torch.int32, device=dev)
+    with pytest.raises(MpxError):
+        eng18.stage_masks(img, seg, torch.ones(65, 1, dtype=torch.uint8, device=dev), 0)      # > max_batch
+    with pytest.raises(MpxError):
+        eng18.stage_masks(img, seg, torch.ones(1, 4096, dtype=torch.uint8, device=dev), 0)    # S too large
+    with pytest.raises(ValueError):
+        eng18.stage_masks(img.float(), seg, torch.ones(1, 1, dtype=torch.uint8, device=dev), 0)
+    with pytest.raises(ValueError):
+        eng18.stage_masks(img, seg.long(), torch.ones(1, 1, dtype=torch.uint8, device=dev), 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv + BN (+ residual) (+ ReLU): every distinct kernel path, against torch CPU fp64
+# ------------------------------------------------------------------------------------------------
+def _conv_reference(sd, d, x_nchw64, res_nchw64):
+    name, bn = d.name.decode(), d.bn_name.decode()
+    w = sd[name + ".weight"].double()
+    y = F.conv2d(x_nchw64, w, None, d.stride, d.pad)
+    scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+    y = (y - sd[bn + ".running_mean"].double().view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + sd[bn + ".bias"].double().view(1, -1, 1, 1)
+    if res_nchw64 is not None:
+        y = y + res_nchw64
+    return F.relu(y) if d.relu else y
+
+
+def _run_conv(eng, i, x_nhwc, res_nhwc, batch):
+    d = eng.layers[i]
+    dev = eng.device
+    xh, xl = split(x_nhwc.to(dev))
+    rh = rl = None
+    if res_nhwc is not None:
+        rh, rl = split(res_nhwc.to(dev))
+    oh = torch.full((batch, d.hout, d.hout, d.cout), float("nan"), dtype=torch.float16, device=dev)
+    ol = torch.full_like(oh, float("nan"))
+    rc = eng._lib.mpx_conv_bn_act(eng._h, i, _p(xh), _p(xl), _p(rh), _p(rl), _p(oh), _p(ol), None, batch, eng._stream())
+    _lib.check(eng._h, rc, "mpx_conv_bn_act")
+    torch.cuda.synchronize()
+    return merge(oh, ol).cpu(), merge(xh, xl).cpu(), (merge(rh, rl).cpu() if rh is not None else None)
+
+
+def _layer_index(eng, name):
+    return [d.name.decode() for d in eng.layers].index(name)
+
+
+R18_LAYERS = ["layer1.0.conv1", "layer1.0.conv2", "layer2.0.conv1", "layer2.0.downsample.0", "layer2.0.conv2",
+              "layer3.1.conv2", "layer4.0.conv1", "layer4.1.conv2"]
+R101_LAYERS = ["layer1.0.conv1", "layer1.0.conv2", "layer1.0.conv3", "layer1.0.downsample.0", "layer1.1.conv1",
+               "layer2.0.conv2", "layer2.0.downsample.0", "layer3.5.conv1", "layer3.5.conv2", "layer3.5.conv3",
+               "layer4.0.conv2", "layer4.2.conv3"]
+
+
+def _check_layer(eng, sd, name, batch=3):
+    i = _layer_index(eng, name)
+    d = eng.layers[i]
+    g = torch.Generator().manual_seed(i)
+    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=g).clamp_min(-0.5) * 1.5     # mostly post-ReLU-like
+    res = torch.randn(batch, d.hout, d.hout, d.cout, generator=g) if d.residual else None
+    got, x_used, res_used = _run_conv(eng, i, x, res, batch)
+    want = _conv_reference(sd, d, x_used.double().permute(0, 3, 1, 2),
+                           res_used.double().permute(0, 3, 1, 2) if res_used is not None else None)
+    want = want.permute(0, 2, 3, 1)
+    assert not torch.isnan(got).any()
+    err = (got.double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= 4e-6 * max(scale, 1.0), "%s: max err %.3e (scale %.2f)" % (name, err, scale)
+
+
+@pytest.mark.parametrize("name", R18_LAYERS)
+def test_conv_layers_resnet18(eng18, name):
+    _check_layer(eng18, synth.make_state_dict("resnet18"), name)
+
+
+@pytest.mark.parametrize("name", R101_LAYERS)
+def test_conv_layers_resnet101(eng101, name):
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name)
+
+
+def test_stem_conv_from_staged_input(eng18, dev):
+    sd = synth.make_state_dict("resnet18")
+    img = synth.make_images(1, kind="noise")[0]
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(3, 196, seed=2)
+    eng18.stage_masks(torch.from_numpy(img).to(dev), torch.from_numpy(seg).to(dev), torch.from_numpy(onoff).to(dev), 0)
+    d = eng18.layers[0]
+    oh = torch.full((3, 112, 112, 64), float("nan"), dtype=torch.float16, device=dev)
+    ol = torch.full_like(oh, float("nan"))
+    rc = eng18._lib.mpx_conv_bn_act(eng18._h, 0, None, None, None, None, _p(oh), _p(ol), None, 3, eng18._stream())
+    _lib.check(eng18._h, rc, "stem")
+    torch.cuda.synchronize()
+    x = scorer.to_tensor_normalize(img)
+    xin = torch.from_numpy(np.stack([scorer.apply_mask(x, scorer.onoff_mask_u8(seg, onoff[i])) for i in range(3)]))
+    want = _conv_reference(sd, d, xin.double(), None).permute(0, 2, 3, 1)
+    got = merge(oh, ol).cpu().double()
+    assert (got - want).abs().max().item() <= 4e-6 * max(want.abs().max().item(), 1.0)
+
+
+def test_conv_argument_errors(eng18, dev):
+    t = torch.zeros(8, dtype=torch.float16, device=dev)
+    lib, h = eng18._lib, eng18._h
+    assert lib.mpx_conv_bn_act(h, 999, _p(t), _p(t), None, None, _p(t), _p(t), None, 1, None) == -1
+    assert lib.mpx_conv_bn_act(h, 1, None, None, None, None, _p(t), _p(t), None, 1, None) == -1     # missing input
+    assert lib.mpx_conv_bn_act(h, 1, _p(t), _p(t), _p(t), None, _p(t), _p(t), None, 1, None) == -1  # half a residual
+    assert lib.mpx_conv_bn_act(h, 0, _p(t), _p(t), None, None, _p(t), _p(t), None, 1, None) == -1   # stem takes staging
+    assert b"conv_bn_act" in lib.mpx_last_error(h)
+
+
+# ------------------------------------------------------------------------------------------------
+# pools and head
+# ------------------------------------------------------------------------------------------------
+def test_maxpool_exact(eng18, dev):
+    x = torch.randn(3, 112, 112, 64, generator=torch.Generator().manual_seed(0)).clamp_min(0)
+    xh, xl = split(x.to(dev))
+    oh = torch.empty(3, 56, 56, 64, dtype=torch.float16, device=dev)
+    ol = torch.empty_like(oh)
+    _lib.check(eng18._h, eng18._lib.mpx_maxpool3x3s2(eng18._h, _p(xh), _p(xl), _p(oh), _p(ol), 3, 112, 64, eng18._stream()), "maxpool")
+    torch.cuda.synchronize()
+    want = F.max_pool2d(merge(xh, xl).cpu().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(merge(oh, ol).cpu(), want)
+
+
+def test_global_avgpool(eng18, dev):
+    x = torch.randn(5, 7, 7, 512, generator=torch.Generator().manual_seed(1)).clamp_min(0)
+    xh, xl = split(x.to(dev))
+    oh = torch.empty(5, 512, dtype=torch.float16, device=dev)
+    ol = torch.empty_like(oh)
+    _lib.check(eng18._h, eng18._lib.mpx_global_avgpool(eng18._h, _p(xh), _p(xl), _p(oh), _p(ol), 5, 49, 512, eng18._stream()), "avgpool")
+    torch.cuda.synchronize()
+    want = merge(xh, xl).cpu().double().mean(dim=(1, 2))
+    assert (merge(oh, ol).cpu().double() - want).abs().max().item() <= 1e-6
+
+
+def test_head_softmax_gather(eng18, dev):
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(9, 1000, generator=g) * 4
+    logits[2, 17] = logits[2].max() + 1
+    label = torch.randint(0, 1000, (9,), generator=g, dtype=torch.int32)
+    label[2] = 17
+    score = torch.empty(9, dtype=torch.float32, device=dev)
+    pred = torch.empty(9, dtype=torch.int32, device=dev)
+    ld, lb = logits.to(dev), label.to(dev)
+    _lib.check(eng18._h, eng18._lib.mpx_head_softmax_gather(eng18._h, _p(ld), _p(lb), _p(score), _p(pred), 9, eng18._stream()), "head")
+    torch.cuda.synchronize()
+    want = torch.softmax(logits.double(), 1)[torch.arange(9), label.long()]
+    assert (score.cpu().double() - want).abs().max().item() <= 2e-7
+    assert torch.equal(pred.cpu().long(), logits.argmax(1))
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end: golden vectors, live oracle, size-independent properties
+# ------------------------------------------------------------------------------------------------
+def _golden_case(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, "scores_%s.npz" % arch))
+    seg = np.load(os.path.join(golden_dir, "segments_blobs.npz"))["segments"][int(g["image_index"])].astype(np.int64)
+    img = synth.make_images(2, seed=int(g["image_seed"]))[int(g["image_index"])]
+    return g, seg, img
+
+
+def test_cfg1_resnet18_64_masks_vs_golden(eng18, golden_dir):
+    """BASELINE cfg-1: ResNet-18, 1 image, 64 superpixel masks."""
+    g, seg, img = _golden_case("resnet18", golden_dir)
+    label = int(g["label"])
+    assert eng18.predict(img)[0] == label
+    onoff, score, pred = eng18.score_masks(img, seg, g["onoff"], label)
+    err = np.abs(score - g["score_f32"]).max()
+    err64 = np.abs(score.astype(np.float64) - g["score_f64"]).max()
+    print("resnet18 cfg-1: max|d| vs fp32 loop %.3e, vs fp64 %.3e" % (err, err64))
+    assert err <= SCORE_TOL and err <= SCORE_TOL_TIGHT
+    assert (pred == g["pred"]).all()
+    assert score.dtype == np.float32 and pred.dtype == np.int32 and onoff is not None
+
+
+def test_resnet101_vs_golden(eng101, golden_dir):
+    g, seg, img = _golden_case("resnet101", golden_dir)
+    label = int(g["label"])
+    assert eng101.predict(img)[0] == label
+    _o, score, pred = eng101.score_masks(img, seg, g["onoff"], label)
+    err = np.abs(score - g["score_f32"]).max()
+    print("resnet101: max|d| vs fp32 loop %.3e, vs fp64 %.3e" % (err, np.abs(score - g["score_f64"]).max()))
+    assert err <= SCORE_TOL and err <= SCORE_TOL_TIGHT
+    assert (pred == g["pred"]).all()
+
+
+def test_resnet18_vs_live_oracle_noise_image(eng18):
+    """Same masks through the normalised-f32 entry (what the reference's val_loader yields)."""
+    sd = synth.make_state_dict("resnet18")
+    img = synth.make_images(3, seed=77, kind="noise")[2]
+    x = scorer.to_tensor_normalize(img)
+    seg = synth.grid_segments()
+    onoff = masks.windows_onoff(196, [0, 1, 60, 118, 196])
+    label = scorer.base_prediction(sd, "resnet18", x)
+    ref, ref_pred = scorer.score_masks_reference_loop(sd, "resnet18", x, seg, onoff, label)
+    _o, s_u8, p_u8 = eng18.score_masks(img, seg, onoff, label)
+    _o, s_f32, p_f32 = eng18.score_masks(x, seg, onoff, label)
+    assert np.abs(s_u8 - ref).max() <= SCORE_TOL_TIGHT and np.abs(s_f32 - ref).max() <= SCORE_TOL_TIGHT
+    assert (s_u8 == s_f32).all()                                   # both entries stage identical bits
+    assert (p_u8 == ref_pred).all() and (p_f32 == ref_pred).all()
+
+
+def test_properties_full_batch(eng18):
+    """Size-independent properties at the engine's full batch (64) and beyond it (chunking)."""
+    imgs = synth.make_images(2, seed=5, kind="noise")
+    seg = synth.grid_segments()
+    label = 123
+    onoff = synth.random_onoff(150, 196, seed=11)          # > max_batch: three chunks
+    onoff[0] = 1
+    onoff[1] = 0
+    onoff[70] = onoff[3]                                    # duplicates in different slots / chunks
+    onoff[149] = onoff[3]
+    _o, s0, p0, lg0 = eng18.score_masks(imgs[0], seg, onoff, label, return_logits=True)
+    _o, s1, _p1 = eng18.score_masks(imgs[1], seg, onoff, label)
+    base_pred, base_prob = eng18.predict(imgs[0])
+    assert s0[0] == base_prob[label] or abs(s0[0] - base_prob[label]) < 1e-7     # all-ones mask == unmasked
+    assert p0[0] == base_pred
+    assert s0[1] == s1[1]                                   # all-zeros mask: independent of the image
+    assert s0[3] == s0[70] == s0[149] and p0[3] == p0[70]   # batch/slot invariance, bit for bit
+    assert np.isfinite(lg0).all() and (s0 >= 0).all() and (s0 <= 1).all()
+    sm = np.exp(lg0 - lg0.max(1, keepdims=True))
+    sm /= sm.sum(1, keepdims=True)
+    assert np.abs(sm[np.arange(150), label] - s0).max() < 1e-6
+    assert (lg0.argmax(1) == p0).all()
+    _o, s_again, _ = eng18.score_masks(imgs[0], seg, onoff, label)
+    assert (s_again == s0).all()                            # deterministic run to run
+
+
+def test_engine_errors(eng18, dev):
+    img = synth.make_images(1)[0]
+    seg = synth.grid_segments()
+    with pytest.raises(ValueError):
+        eng18.score_masks(img, seg, np.ones((2, 195), dtype=np.uint8), 0)      # S mismatch
+    with pytest.raises(ValueError):
+        eng18.score_masks(img[:100], seg, np.ones((2, 196), dtype=np.uint8), 0)
+    with pytest.raises(ValueError):
+        eng18.score_masks(img, seg, np.ones((2, 196), dtype=np.uint8), 1000)
+    o, s, p = eng18.score_masks(img, seg, np.zeros((0, 196), dtype=np.uint8), 0)   # empty batch
+    assert s.shape == (0,) and p.shape == (0,)
+    labels = torch.zeros(65, dtype=torch.int32, device=dev)
+    with pytest.raises(MpxError):
+        eng18.forward(65, labels)                                               # > max_batch
+    with pytest.raises(ValueError):
+        MaskedForwardEngine("vgg16")
+    fresh = MaskedForwardEngine("resnet18", max_batch=2, device=0)
+    with pytest.raises(MpxError):
+        fresh.forward(1, labels[:1])                                            # weights not loaded
+    with pytest.raises(KeyError):
+        fresh.load_state_dict({})
+    fresh.close()

@@ -1,0 +1,227 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mpx.h declares, the
+host-only weight packer, mask-vector logic, segment ranking, sharding math and the reference-named
+API driven by a fake engine (no GPU compute anywhere in this file)."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from network_interpretation_imagenet_amd import _lib, api, masks, shard, synth
+from network_interpretation_imagenet_amd.engine import rank_segments
+from oracle import resnet_ref, scorer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(mpx_lib):
+    header = open(os.path.join(ROOT, "include", "mpx.h")).read()
+    declared = set(re.findall(r"(?m)^(?:int|const char\*|size_t|double)\s+(mpx_[a-z0-9_]+)\(", header))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(mpx_lib, name) is not None
+
+
+def test_null_engine_calls_fail_cleanly(mpx_lib):
+    assert mpx_lib.mpx_num_convs(None) == -1
+    assert mpx_lib.mpx_forward(None, None, None, None, None, 1, None) == -1
+    assert mpx_lib.mpx_destroy(None) == 0
+    assert mpx_lib.mpx_last_error(None) == b"null engine"
+
+
+def _desc(cin, cout, k):
+    d = _lib.ConvDesc()
+    d.cin, d.cout, d.ksize = cin, cout, k
+    d.k_packed = 7 * 32 if cin == 3 else k * k * cin
+    d.cout_pad = (cout + 127) // 128 * 128
+    return d
+
+
+def _pack(mpx_lib, d, w, bn):
+    hi = np.zeros((d.cout_pad, d.k_packed), dtype=np.uint16)
+    lo = np.zeros_like(hi)
+    sc = np.zeros(d.cout_pad, dtype=np.float32)
+    sh = np.zeros(d.cout_pad, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    rc = mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5,
+                                       p(hi), p(lo), p(sc), p(sh))
+    assert rc == 0
+    return hi.view(np.float16), lo.view(np.float16), sc, sh
+
+
+@pytest.mark.parametrize("cin,cout,k", [(64, 64, 3), (256, 128, 1), (3, 64, 7)])
+def test_pack_conv_weights(mpx_lib, cin, cout, k):
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
+    w[3] = 0.0                                            # an all-zero output channel
+    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
+          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2, cout).astype(np.float32)]
+    d = _desc(cin, cout, k)
+    hi, lo, sc, sh = _pack(mpx_lib, d, w, bn)
+    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
+    np.testing.assert_allclose(sh[:cout], bn[1] - bn[2] * s, rtol=1e-6, atol=1e-7)
+    assert (hi[cout:] == 0).all() and (sc[cout:] == 0).all()
+    ratio = sc[:cout].astype(np.float64) / s               # = 2^-e, an exact power of two
+    e = -np.log2(ratio)
+    assert np.allclose(e, np.round(e), atol=1e-6) and round(e[3]) == 0
+    if cin == 3:     # stem: k = ky*32 + px*4 + c, pads are zero
+        wk = np.zeros((cout, 7, 8, 4), dtype=np.float32)
+        wk[:, :, :7, :3] = w.transpose(0, 2, 3, 1)
+        wk = wk.reshape(cout, -1)
+    else:            # (ky,kx,ci), ci fastest
+        wk = w.transpose(0, 2, 3, 1).reshape(cout, -1)
+    scaled = wk.astype(np.float64) * (2.0 ** np.round(e))[:, None]
+    amax = np.abs(scaled).max(1)
+    assert ((amax[np.arange(cout) != 3] >= 512) & (amax[np.arange(cout) != 3] < 1024)).all()
+    rec = hi[:cout].astype(np.float64) + lo[:cout].astype(np.float64)
+    # split-fp16 keeps >= 21 bits of every weight relative to the channel maximum's exponent
+    assert np.abs(rec - scaled).max() <= 1024 * 2.0 ** -21
+    assert (hi[:cout] == scaled.astype(np.float32).astype(np.float16)).all()
+
+
+def test_pack_fc(mpx_lib):
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((1000, 512)).astype(np.float32)
+    b = rng.standard_normal(1000).astype(np.float32)
+    d = _desc(512, 1000, 1)
+    hi, lo, sc, sh = _pack(mpx_lib, d, w, [None, b, None, None])
+    assert (sh[:1000] == b).all() and (sh[1000:] == 0).all()
+    rec = (hi[:1000].astype(np.float64) + lo[:1000]) * sc[:1000, None]
+    np.testing.assert_allclose(rec, w, rtol=0, atol=2e-6)
+
+
+def test_pack_rejects_bad_desc(mpx_lib):
+    d = _desc(64, 64, 3)
+    d.k_packed = 100
+    w = np.zeros((64, 64, 3, 3), dtype=np.float32)
+    z = np.zeros(64, dtype=np.float32)
+    buf = np.zeros((128, 576), dtype=np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(z), p(z), p(z), p(z), 1e-5, p(buf), p(buf), p(z), p(z)) == -1
+
+
+def test_rank_segments():
+    seg = np.full((224, 224), 40, dtype=np.int64)
+    seg[:10] = 7
+    seg[100:, 50:] = 1000
+    rank, s = rank_segments(seg)
+    assert s == 3 and rank.dtype == np.int32
+    assert rank[0, 0] == 0 and rank[50, 0] == 1 and rank[150, 100] == 2
+    with pytest.raises(ValueError):
+        rank_segments(np.zeros((10, 10), dtype=np.int32))
+    with pytest.raises(ValueError):
+        rank_segments(np.zeros((224, 224), dtype=np.float32))
+
+
+def test_masks_module():
+    assert masks.window_size(196) == 78 and masks.bo_upper_bound(196) == 117
+    assert masks.window_onoff(10, 8).tolist() == [0] * 8 + [1, 1]          # truncated at the end
+    assert masks.windows_onoff(10, [0, 3]).shape == (2, 10)
+    draws = masks.draw_first_indices(46, 500, random.Random(3))
+    assert min(draws) >= 1 and max(draws) <= 46 - 18
+    with pytest.raises(ValueError):
+        masks.draw_first_indices(0, 1)
+
+
+def test_shard_blocks_and_ranges():
+    for total, world in [(10, 3), (65536 * 8, 8), (7, 8), (512, 1)]:
+        blocks = [shard.block(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+    assert shard.image_ranges(5, 25, 10) == [(0, 5, 10), (1, 0, 10), (2, 0, 5)]
+    assert shard.image_ranges(20, 20, 10) == []
+    with pytest.raises(ValueError):
+        shard.block(10, 3, 3)
+
+
+class FakeEngine:
+    """Engine stand-in for API plumbing tests: scores through the CPU oracle."""
+
+    def __init__(self, arch="resnet18"):
+        self.arch, self.sd, self.calls = arch, synth.make_state_dict(arch), 0
+
+    def predict(self, image):
+        x = torch.as_tensor(image)
+        with torch.no_grad():
+            logits = resnet_ref.forward(self.sd, x[None], self.arch)
+        return int(logits.argmax()), torch.softmax(logits, 1)[0].numpy()
+
+    def score_masks(self, image, segments, onoff, label):
+        self.calls += 1
+        s, p = scorer.score_masks_batched(self.sd, self.arch, torch.as_tensor(image), segments, onoff, label, chunk=16)
+        return onoff, s.astype(np.float32), p.astype(np.int32)
+
+
+@pytest.fixture()
+def coarse_setup(tmp_path):
+    eng = FakeEngine()
+    x = scorer.to_tensor_normalize(synth.make_images(1)[0])
+    label, _ = eng.predict(x)
+    loader = [(torch.zeros(1, 3, 224, 224), torch.tensor([0])), (x[None], torch.tensor([label]))]
+    seg = synth.grid_segments(block=56)               # 16 superpixels -> 17 window starts, k = 6
+    api.configure(eval_img_index=2, num_mask_samples=12, segmenter=lambda img: seg, mask_dir=str(tmp_path / "masks"), seed=5)
+    yield eng, loader, seg, label, tmp_path / "masks"
+    api.configure(eval_img_index=1, num_mask_samples=100, segmenter=None, mask_dir=None, seed=None)
+
+
+def test_api_drop_in_signatures(coarse_setup):
+    eng, loader, seg, label, mask_dir = coarse_setup
+    criterion = object()
+    y = api.sample_loss([3.7], loader, eng, criterion)           # L-BFGS-B hands floats: int() truncates
+    assert isinstance(y, np.float32)
+    y2 = api.validate_nueral_network(loader, eng, criterion, 3.7, 3)
+    assert y == y2 and eng.calls == 1                            # served from the one-pass table
+    ref, _ = scorer.score_masks_reference_loop(eng.sd, eng.arch, loader[1][0][0], seg, scorer.window_onoff(16, 3)[None], label)
+    assert abs(float(y) - float(ref[0])) < 1e-6
+    m = api.superpixel_mask(3)
+    assert m.dtype == np.uint8 and set(np.unique(m)) <= {0, 255}
+    assert (m == scorer.window_mask_u8(seg, 3) * 255).all()
+    names = sorted(os.listdir(mask_dir))
+    assert names and all(re.fullmatch(r"mask_3\.7_[01]\.png", n) for n in names)
+    from PIL import Image
+    assert (np.array(Image.open(mask_dir / names[0])) == m).all()
+
+
+def test_api_bo_style_caller(coarse_setup):
+    """bayesian_optimisation(n_iters, sample_loss, val_loader, nn_model, criterion, bounds, n_pre_samples)
+    calls sample_loss(params, val_loader, nn_model, criterion) (BayesianOptimization.py:137-144,182)."""
+    eng, loader, _seg, _label, _ = coarse_setup
+    ub = masks.bo_upper_bound(16)
+    rng = random.Random(0)
+    xs, ys = [], []
+    for _ in range(5):
+        params = [rng.randint(0, ub)]
+        xs.append(params)
+        ys.append(api.sample_loss(params, loader, eng, None))
+    xp, yp = np.array(xs), np.array(ys)
+    assert xp.shape == (5, 1) and yp.shape == (5,) and eng.calls == 1
+
+
+def test_api_validate_generators(coarse_setup):
+    eng, loader, seg, label, mask_dir = coarse_setup
+    n_ok = api.validate(loader, eng, None, 2)
+    assert isinstance(n_ok, int) and 0 <= n_ok <= 12
+    files = sorted(os.listdir(mask_dir))
+    assert len(files) == 12 and sum(f.endswith("_1.png") for f in files) == n_ok
+    summed = api.validate_summed(loader, eng, None, 2)
+    assert summed.shape == (224, 224) and summed.dtype == np.float64
+    # same seed -> same draws: compare with the oracle's literal accumulation
+    firsts = masks.draw_first_indices(16, 12, random.Random(5))
+    onoff = masks.windows_onoff(16, firsts)
+    _s, pred = scorer.score_masks_batched(eng.sd, eng.arch, loader[1][0][0], seg, onoff, label)
+    assert (summed == scorer.summed_superpixel_labels(seg, onoff, pred == label)).all()
+    assert int((pred == label).sum()) == n_ok
+
+
+def test_api_wrong_base_prediction(coarse_setup):
+    eng, loader, _seg, label, _ = coarse_setup
+    bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
+    with pytest.raises(api.BasePredictionWrong):
+        api.sample_loss([1], bad, eng, None)
+    assert api.validate(bad, eng, None, 2) == 0
+    assert api.validate(loader, eng, None, 5) == 0                # index past the end of the loader

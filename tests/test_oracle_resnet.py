@@ -1,0 +1,84 @@
+"""Known answers that pin the CPU oracle's ResNet restatement.  The reference
+ships no tests or fixtures for this path (parity unpinned), so these are the anchors."""
+import numpy as np
+import pytest
+import torch
+
+from network_interpretation_imagenet_amd import synth
+from oracle import resnet_ref as R
+
+
+@pytest.mark.parametrize("arch,params,macs,nconv", [
+    ("resnet18", 11689512, 1813561344, 20),
+    ("resnet101", 44549160, 7799357440, 104),
+])
+def test_known_counts(arch, params, macs, nconv):
+    assert R.learnable_param_count(arch) == params
+    assert R.conv_macs(arch) == macs
+    assert len(R.conv_list(arch)) == nconv
+    assert R.flops_per_forward(arch) == 2 * (macs + 1000 * R.feature_dim(arch))
+
+
+def test_flops_match_baseline_md():
+    assert R.flops_per_forward("resnet18") == 3628146688
+    assert R.flops_per_forward("resnet101") == 15602810880
+
+
+def test_resnet101_dominant_shapes():
+    shapes = {}
+    for _n, cin, cout, k, s, _p, h in R.conv_list("resnet101"):
+        shapes[(cin, cout, k, s, h)] = shapes.get((cin, cout, k, s, h), 0) + 1
+    assert shapes[(256, 1024, 1, 1, 14)] == 23
+    assert shapes[(1024, 256, 1, 1, 14)] == 22
+    assert shapes[(256, 256, 3, 1, 14)] == 22
+    assert len(shapes) == 23
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_synth_state_dict_has_torchvision_keys(arch):
+    sd = synth.make_state_dict(arch)
+    want = R.state_dict_shapes(arch)
+    assert list(sd.keys()) == list(want.keys())
+    for k, shp in want.items():
+        assert tuple(sd[k].shape) == shp and sd[k].dtype == torch.float32
+    assert "layer1.0.downsample.0.weight" in sd if arch == "resnet50" else "layer1.0.downsample.0.weight" not in sd
+    assert "layer2.0.downsample.1.running_var" in sd
+
+
+def test_forward_shape_softmax_and_taps():
+    arch = "resnet18"
+    sd = synth.make_state_dict(arch)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    taps = {}
+    with torch.no_grad():
+        logits = R.forward(sd, x, arch, taps)
+    assert logits.shape == (2, 1000)
+    assert taps["conv1"].shape == (2, 64, 112, 112) and taps["maxpool"].shape == (2, 64, 56, 56)
+    assert taps["layer4.1"].shape == (2, 512, 7, 7) and taps["avgpool"].shape == (2, 512)
+    assert (taps["layer2.0"] >= 0).all()
+    p = torch.softmax(logits, 1)
+    assert torch.allclose(p.sum(1), torch.ones(2), atol=1e-6)
+    # peaked but unsaturated synthetic weights (otherwise a 1e-4 score check is vacuous)
+    assert 0.01 < float(p.max()) < 0.99
+
+
+def test_fp64_mode_bounds_fp32_noise():
+    arch = "resnet18"
+    sd = synth.make_state_dict(arch)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        l32 = R.forward(sd, x, arch)
+        l64 = R.forward(R.cast_state_dict(sd, torch.float64), x.double(), arch)
+    assert float((l32.double() - l64).abs().max()) < 1e-4
+
+
+def test_bn_is_eval_mode_running_stats():
+    """A constant shift of running_mean must shift the pre-activation exactly (no batch statistics)."""
+    arch = "resnet18"
+    sd = synth.make_state_dict(arch)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    y = R._conv_bn(sd, x, "conv1", 2, 3, False)
+    manual = torch.nn.functional.conv2d(x, sd["conv1.weight"], None, 2, 3)
+    scale = sd["bn1.weight"] / torch.sqrt(sd["bn1.running_var"] + 1e-5)
+    manual = (manual - sd["bn1.running_mean"].view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)
+    assert torch.allclose(y, manual, atol=1e-5)
