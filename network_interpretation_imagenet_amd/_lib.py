@@ -3,6 +3,11 @@ missing or a call fails, this module raises."""
 import ctypes as C
 import os
 
+# torch first: PyTorch-ROCm ships its own libamdhip64; libmpx.so must bind to that one runtime (the
+# one that owns the tensors and streams it is handed).  Loading libmpx.so before torch would pull
+# /opt/rocm's copy into the process and the two runtimes do not share devices or streams.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpx.so")
 

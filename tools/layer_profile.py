@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-layer conv timing (HIP events inside the engine) for one forward batch.
+usage: python tools/layer_profile.py [arch] [batch] [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from network_interpretation_imagenet_amd import synth  # noqa: E402
+from network_interpretation_imagenet_amd.engine import MaskedForwardEngine  # noqa: E402
+
+arch = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device("cuda", 0)
+eng = MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(synth.make_state_dict(arch))
+img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
+seg = torch.from_numpy(synth.grid_segments()).to(dev)
+onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
+labels = torch.zeros(batch, dtype=torch.int32, device=dev)
+for _ in range(2):
+    eng.stage_masks(img, seg, onoff, 0)
+    eng.forward(batch, labels)
+torch.cuda.synchronize()
+eng.profile(True)
+for _ in range(reps):
+    eng.stage_masks(img, seg, onoff, 0)
+    eng.forward(batch, labels)
+eng.profile(False)
+prof = eng.collect_profile()
+tot = 0.0
+groups = {}
+print("%-26s %5s %5s %2s %2s %4s %9s %9s %8s" % ("layer", "cin", "cout", "k", "s", "hout", "ms", "GFLOP", "TFLOP/s"))
+for d, ms in zip(eng.layers, prof["per_conv_ms"]):
+    ms /= reps
+    fl = 2.0 * batch * d.hout * d.hout * d.cout * d.cin * d.ksize * d.ksize
+    key = (d.cin, d.cout, d.ksize, d.stride, d.hout)
+    a = groups.setdefault(key, [0, 0.0, 0.0])
+    a[0] += 1
+    a[1] += ms
+    a[2] += fl
+    tot += ms
+print("-- grouped by shape --")
+for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+    print("%5d->%-5d k%d s%d out%-4d x%-3d %8.3f ms %5.1f%% %8.1f TFLOP/s" % (key[0], key[1], key[2], key[3], key[4], n, ms, 100 * ms / tot, fl / ms / 1e9))
+allfl = eng.flops_per_forward * batch
+print("conv total %.3f ms/batch -> %.1f TFLOP/s algorithmic; other kinds ms/batch: %s" % (
+    tot, allfl / tot / 1e9, {k: round(v / reps, 3) for k, v in prof["ms"].items()}))
