@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_EVERY = 8               # HIP-event bracketing on every 8th image batch of the timed region
+PROFILE_EVERY = 4               # HIP-event bracketing on every 4th forward batch of the timed region
 
 
 def parse():
@@ -36,7 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--images", type=int, default=128, help="images per GPU per step")
-    ap.add_argument("--masks", type=int, default=512, help="masks per image (= forward batch)")
+    ap.add_argument("--masks", type=int, default=512, help="masks per image")
+    ap.add_argument("--images-per-forward", type=int, default=4,
+                    help="images whose masks share one forward batch (batch = this x masks; larger batches fill "
+                         "256 CUs with fewer partial rounds of tiles)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -77,8 +80,11 @@ def main():
     from network_interpretation_imagenet_amd import shard, synth
     from network_interpretation_imagenet_amd.engine import MaskedForwardEngine
 
-    n_img, n_mask = args.images, args.masks
-    eng = MaskedForwardEngine(args.arch, max_batch=n_mask, device=local_rank)
+    n_img, n_mask, ipf = args.images, args.masks, args.images_per_forward
+    if n_img % ipf:
+        raise SystemExit("--images must be a multiple of --images-per-forward")
+    batch = ipf * n_mask
+    eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank)
     eng.load_state_dict(synth.make_state_dict(args.arch))
     # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
     # per-image Bernoulli(0.4) mask-vectors, labels = unmasked argmax (the reference's correctness gate)
@@ -87,9 +93,11 @@ def main():
     onoff = torch.from_numpy(synth.random_onoff(n_img * n_mask, 196, seed=4321 + rank)).view(n_img, n_mask, 196).to(dev)
     ones = torch.ones(1, 196, dtype=torch.uint8, device=dev)
     labels = []
-    for i in range(n_img):
-        eng.stage_masks(imgs[i], seg, ones, 0)
-        _s, p = eng.forward(1, torch.zeros(1, dtype=torch.int32, device=dev))
+    for i0 in range(0, n_img, batch):          # unmasked forwards, one slot per image
+        nb = min(batch, n_img - i0)
+        for j in range(nb):
+            eng.stage_masks(imgs[i0 + j], seg, ones, j)
+        _s, p = eng.forward(nb, torch.zeros(nb, dtype=torch.int32, device=dev))
         labels.append(p)
     labels = torch.cat(labels)
     label_rows = labels.view(n_img, 1).expand(n_img, n_mask).contiguous()
@@ -97,13 +105,14 @@ def main():
     total = world * n_img * n_mask
 
     def step(profile):
-        for i in range(n_img):
-            prof = profile and (i % PROFILE_EVERY == 0)
+        for f, i0 in enumerate(range(0, n_img, ipf)):
+            prof = profile and (f % PROFILE_EVERY == 0)
             if prof:
                 eng.profile(True)
-            eng.stage_masks(imgs[i], seg, onoff[i], 0)
-            s, _p = eng.forward(n_mask, label_rows[i])
-            scores[i] = s
+            for j in range(ipf):
+                eng.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
+            s, _p = eng.forward(batch, label_rows[i0:i0 + ipf].view(-1))
+            scores[i0:i0 + ipf] = s.view(ipf, n_mask)
             if prof:
                 eng.profile(False)
         if world > 1:
@@ -139,7 +148,7 @@ def main():
         conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
         n_conv_layers = len(eng.layers)
         batches_profiled = conv_n / n_conv_layers if n_conv_layers else 0
-        flops_per_batch = eng.flops_per_forward * n_mask
+        flops_per_batch = eng.flops_per_forward * batch
         roofline = None
         if conv_n:
             # dominant kernel = conv_f16x3_kernel (all conv/fc launches).  achieved = algorithmic FLOPs
@@ -158,7 +167,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (BASELINE configs[2]; x%d GPUs)" % (args.arch, n_mask, n_img, world),
-                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": n_mask,
+                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch,
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,

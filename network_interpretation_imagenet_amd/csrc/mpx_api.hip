@@ -232,8 +232,8 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     const int n_tiles_p = (p.M + TP - 1) / TP;
     const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
-    const size_t lds = 2 * (size_t)(TC + TP) * 128;
-    hipLaunchKernelGGL((conv_f16x3_kernel<TC, TP>), dim3((unsigned)nblocks), dim3(256), lds, st, p);
+    constexpr size_t lds = conv_lds_bytes<TC, TP>();
+    hipLaunchKernelGGL((conv_f16x3_kernel<TC, TP>), dim3((unsigned)nblocks), dim3(CONV_THREADS), lds, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
@@ -266,8 +266,8 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
     p.M = (int)M;
     ProfScope ps(h, st, OP_CONV, i);
-    if (L.d.cout >= 128) return launch_conv_tile<128, 128>(h, p, L.d.cout_pad, st);
-    return launch_conv_tile<64, 128>(h, p, L.d.cout_pad, st);
+    if (L.d.cout >= 128) return launch_conv_tile<128, 256>(h, p, L.d.cout_pad, st);
+    return launch_conv_tile<64, 256>(h, p, L.d.cout_pad, st);
 }
 
 }  // namespace
@@ -377,9 +377,11 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     e = hipMemset(h->arena, 0, 256 + 2 * in_plane);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                conv_lds_bytes<128, 256>());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<64, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                conv_lds_bytes<64, 256>());
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
     *out = h;
     return 0;

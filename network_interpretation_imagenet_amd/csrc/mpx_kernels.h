@@ -7,225 +7,9 @@
 // fp32 accumulation (v_mfma_f32_16x16x32_f16), which reproduces fp32 convolution to ~1e-7
 // relative (oracle/precision_study.py) at 1/3 of the fp16 MFMA rate = 5.3x the f32 MFMA rate.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "mpx_conv.h"
 
 namespace mpx {
-
-typedef _Float16 half_t;
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-#define MPX_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define MPX_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-__device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
-    hi = (half_t)v;
-    lo = (half_t)(v - (float)hi);
-}
-
-// ------------------------------------------------------------------------------------------
-// K1/K2: conv (implicit GEMM) + per-channel scale/shift (BatchNorm) + residual + ReLU + split
-// ------------------------------------------------------------------------------------------
-struct ConvParams {
-    const half_t* x_hi;      // input planes, NHWC (pix_stride elements per pixel)
-    const half_t* x_lo;
-    const half_t* w_hi;      // packed weights [cout_pad][ktot]
-    const half_t* w_lo;
-    const float* scale;      // [cout_pad]
-    const float* shift;
-    const half_t* r_hi;      // residual planes [M][cout] or null
-    const half_t* r_lo;
-    half_t* y_hi;            // output planes [M][cout]
-    half_t* y_lo;
-    float* y_f32;            // fp32 output [M][cout] (fc) or null
-    const half_t* zero_page; // >= 64 zero bytes, 16-B aligned
-    int hin, win;            // input spatial extent the bounds check uses
-    int pix_stride;          // fp16 elements between adjacent input pixels
-    int ho, wo;
-    int kh, kw, stride, pad;
-    int k_per_tap;           // K contributed by one (ky,kx) tap (= cin; 32 for the stem)
-    int ktot;                // kh*kw*k_per_tap
-    int cout;                // real output channels (store bound and row pitch of y/r)
-    int M;                   // B*ho*wo output pixels
-    int n_tiles_c;           // cout_pad / TC
-    int relu;
-};
-
-// One workgroup = 4 waves (2x2) computes a TC(cout) x TP(pixel) tile; K advances 32 per step.
-// LDS stage = [W_hi TCx64B][W_lo TCx64B][X_hi TPx64B][X_lo TPx64B], double buffered and filled by
-// global_load_lds_dwordx4 (lane-linear destination).  Rows are 64 B, so a ds_read_b128 of
-// MFMA fragments would be 2-way bank conflicted; the 16-B chunk index is XORed with
-// ((row>>3)&1)<<1, applied on the SOURCE address of the DMA and on the fragment read.
-template <int TC, int TP>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CF = TC / 32;           // 16-row cout fragments per wave
-    constexpr int PF = TP / 32;           // 16-col pixel fragments per wave
-    constexpr int WCH = TC * 4 / 256;     // 16-B chunks per thread per W plane per step
-    constexpr int XCH = TP * 4 / 256;
-    constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = TC * 128, OFF_XLO = TC * 128 + TP * 64;
-    constexpr int STAGE = (TC + TP) * 128;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // XCD-aware bijective remap: blocks that share an XCD (b % 8) walk a contiguous range of
-    // logical tiles, cout tiles fastest, so the X tile of one pixel range stays in that XCD's L2.
-    int L;
-    {
-        const int nb = gridDim.x, b = blockIdx.x;
-        const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7;
-        L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    }
-    const int mt = L / p.n_tiles_c;
-    const int nt = L - mt * p.n_tiles_c;
-    const int m0 = mt * TP, n0 = nt * TC;
-
-    // ---- per-thread staging bookkeeping ----
-    int x_pixbase[XCH], x_iy0[XCH], x_ix0[XCH], x_q[XCH];
-    const int howo = p.ho * p.wo;
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id >> 2;
-        x_q[i] = ((id & 3) ^ (((row >> 3) & 1) << 1)) * 8;
-        const int m = m0 + row;
-        const int n = m / howo;
-        const int rem = m - n * howo;
-        const int oy = rem / p.wo;
-        const int ox = rem - oy * p.wo;
-        x_pixbase[i] = n * p.hin * p.win;
-        x_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
-        x_ix0[i] = ox * p.stride - p.pad;
-    }
-    size_t w_off[WCH];
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id >> 2;
-        w_off[i] = (size_t)(n0 + row) * p.ktot + ((id & 3) ^ (((row >> 3) & 1) << 1)) * 8;
-    }
-
-    auto stage = [&](int buf, int ks, int ky, int kx, int c0) {
-        char* sb = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const size_t o = w_off[i] + (size_t)ks * 32;
-            const int d = (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(p.w_hi + o), MPX_LDS_PTR(sb + OFF_WHI + d), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(p.w_lo + o), MPX_LDS_PTR(sb + OFF_WLO + d), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
-            const size_t o = (size_t)(x_pixbase[i] + iy * p.win + ix) * p.pix_stride + c0 + x_q[i];
-            const half_t* s_hi = ok ? p.x_hi + o : p.zero_page;
-            const half_t* s_lo = ok ? p.x_lo + o : p.zero_page;
-            const int d = (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(s_hi), MPX_LDS_PTR(sb + OFF_XHI + d), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(s_lo), MPX_LDS_PTR(sb + OFF_XLO + d), 16, 0, 0);
-        }
-    };
-
-    f4 acc[CF][PF];
-#pragma unroll
-    for (int a = 0; a < CF; ++a)
-#pragma unroll
-        for (int b = 0; b < PF; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.ktot >> 5;
-    int ky = 0, kx = 0, c0 = 0;     // coordinates of the NEXT step to stage
-    auto advance = [&]() {
-        c0 += 32;
-        if (c0 == p.k_per_tap) {
-            c0 = 0;
-            if (++kx == p.kw) { kx = 0; ++ky; }
-        }
-    };
-
-    stage(0, 0, ky, kx, c0);
-    advance();
-    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-
-    const int lrow = lane & 15;
-    const int qsw = ((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16;
-    const int a_off = (wr * (TC / 2) + lrow) * 64 + qsw;
-    const int b_off = (wc * (TP / 2) + lrow) * 64 + qsw;
-
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-            stage(cur ^ 1, ks + 1, ky, kx, c0);
-            advance();
-        }
-        const char* sb = smem + cur * STAGE;
-        h8 a_hi[CF], a_lo[CF], b_hi[PF], b_lo[PF];
-#pragma unroll
-        for (int a = 0; a < CF; ++a) {
-            a_hi[a] = *(const h8*)(sb + OFF_WHI + a_off + a * 1024);
-            a_lo[a] = *(const h8*)(sb + OFF_WLO + a_off + a * 1024);
-        }
-#pragma unroll
-        for (int b = 0; b < PF; ++b) {
-            b_hi[b] = *(const h8*)(sb + OFF_XHI + b_off + b * 1024);
-            b_lo[b] = *(const h8*)(sb + OFF_XLO + b_off + b * 1024);
-        }
-#pragma unroll
-        for (int a = 0; a < CF; ++a)
-#pragma unroll
-            for (int b = 0; b < PF; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[a], b_lo[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[a], b_hi[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[a], b_hi[b], acc[a][b], 0, 0, 0);
-            }
-        __syncthreads();
-    }
-
-    // ---- epilogue: D row = cout (lane>>4)*4 + reg, D col = pixel lane&15 ----
-#pragma unroll
-    for (int a = 0; a < CF; ++a) {
-        const int co = n0 + wr * (TC / 2) + a * 16 + (lane >> 4) * 4;
-        if (co >= p.cout) continue;
-        const f4 sc = *(const f4*)(p.scale + co);
-        const f4 sh = *(const f4*)(p.shift + co);
-#pragma unroll
-        for (int b = 0; b < PF; ++b) {
-            const int pix = m0 + wc * (TP / 2) + b * 16 + lrow;
-            if (pix >= p.M) continue;
-            const size_t o = (size_t)pix * p.cout + co;
-            f4 v = acc[a][b] * sc + sh;
-            if (p.r_hi) {
-                const h4 rh = *(const h4*)(p.r_hi + o);
-                const h4 rl = *(const h4*)(p.r_lo + o);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j] + (float)rl[j];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (p.y_f32) {
-                *(f4*)(p.y_f32 + o) = v;
-            } else {
-                h4 oh, ol;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    half_t hi, lo;
-                    split_f32(v[j], hi, lo);
-                    oh[j] = hi;
-                    ol[j] = lo;
-                }
-                *(h4*)(p.y_hi + o) = oh;
-                *(h4*)(p.y_lo + o) = ol;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // K0: mask-apply + normalise.  One thread = one pixel; a block stages the on/off rows of MT masks
