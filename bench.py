@@ -41,6 +41,8 @@ def parse():
                     help="images whose masks share one forward batch (batch = this x masks; larger batches fill "
                          "256 CUs with fewer partial rounds of tiles)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
     return ap.parse_args()
 
 
@@ -71,9 +73,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
 
     import __graft_entry__ as g
     g.build()
@@ -115,12 +119,12 @@ def main():
             scores[i0:i0 + ipf] = s.view(ipf, n_mask)
             if prof:
                 eng.profile(False)
-        if world > 1:
+        if use_dist:
             return shard.all_gather_blocks(scores.view(-1), total)
         return scores.view(-1)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +141,7 @@ def main():
                 prof[key][k] = prof[key].get(k, 0) + v
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -175,7 +179,7 @@ def main():
         }
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

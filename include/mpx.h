@@ -77,6 +77,12 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamm
                          const float* beta, const float* mean, const float* var, float eps);
 int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has weights */
 
+/* Kernel variant of layer i (tuning / test hook; results are identical up to fp32 summation order):
+ * 0 = 128x256 tile, 8 waves, 3-stage LDS ring (1 workgroup per CU); 1 = 64x256 (cout <= 64);
+ * 2 = 128x128, 4 waves, 2-stage ring (2 workgroups per CU); 3 = 64x128.  tile < 0 restores the default. */
+int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
+int mpx_get_conv_tile(const mpx_engine* h, int i);
+
 /* Host-only packer (no GPU needed; what mpx_set_conv_weights runs before the upload).
  * Produces the fp16 planes w_hi/w_lo [cout_pad][k_packed] (k order = (ky,kx,ci), ci fastest;
  * for the 7x7 stem k = ky*32 + px*4 + c over the NHWC4 padded input), each output channel

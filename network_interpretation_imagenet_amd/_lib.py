@@ -42,6 +42,8 @@ SIGNATURES = {
     "mpx_conv_info": (_i, [_vp, _i, C.POINTER(ConvDesc)]),
     "mpx_set_conv_weights": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f]),
     "mpx_weights_complete": (_i, [_vp]),
+    "mpx_set_conv_tile": (_i, [_vp, _i, _i]),
+    "mpx_get_conv_tile": (_i, [_vp, _i]),
     "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -34,6 +34,7 @@ struct ConvLayer {
     bool loaded = false;
     bool is_fc = false;
     bool is_stem = false;
+    int tile = 0;           // ConvTile<n> variant (mpx_set_conv_tile)
 };
 
 struct Op {
@@ -102,6 +103,8 @@ void set_name(char* dst, const std::string& s) {
     std::snprintf(dst, 48, "%s", s.c_str());
 }
 
+int default_tile(const mpx_conv_desc& d);
+
 // torchvision ResNet topology (models/resnet.py, un-vendored): conv list and op list.
 int build_topology(mpx_engine* h) {
     int depths[4];
@@ -126,6 +129,7 @@ int build_topology(mpx_engine* h) {
         L.is_stem = (cin == 3);
         L.d.k_packed = L.is_stem ? kStemK * 32 : k * k * cin;
         L.d.cout_pad = (int)round_up(cout, 128);
+        L.tile = default_tile(L.d);
         h->convs.push_back(L);
         return (int)h->convs.size() - 1;
     };
@@ -226,16 +230,24 @@ struct ProfScope {
     }
 };
 
-template <int TC, int TP>
+template <class Cfg>
 int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
-    p.n_tiles_c = cout_pad / TC;
-    const int n_tiles_p = (p.M + TP - 1) / TP;
+    p.n_tiles_c = cout_pad / Cfg::TC;
+    const int n_tiles_p = (p.M + Cfg::TP - 1) / Cfg::TP;
     const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
-    constexpr size_t lds = conv_lds_bytes<TC, TP>();
-    hipLaunchKernelGGL((conv_f16x3_kernel<TC, TP>), dim3((unsigned)nblocks), dim3(CONV_THREADS), lds, st, p);
+    hipLaunchKernelGGL(conv_f16x3_kernel<Cfg>, dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
+}
+
+// Default variant per layer, from tools/tile_sweep.sh on MI355X at batch 2048 (profiles/r01_tile_sweep_b2048.txt):
+// the 128x128 tile with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound
+// epilogue overlaps the other's K loop) and on cout = 64 layers even though half of its MFMA rows multiply zero
+// padding (a K step has a fixed cost that the 64-row tiles do not amortise); wide 3x3 layers are within noise
+// on both big tiles and keep the 128x256 tile (fewest L2 bytes per FLOP).  Tiles 1, 3 stay selectable.
+int default_tile(const mpx_conv_desc& d) {
+    return (d.ksize == 3 && d.cout >= 128) ? 0 : 2;
 }
 
 int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
@@ -266,8 +278,12 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
     p.M = (int)M;
     ProfScope ps(h, st, OP_CONV, i);
-    if (L.d.cout >= 128) return launch_conv_tile<128, 256>(h, p, L.d.cout_pad, st);
-    return launch_conv_tile<64, 256>(h, p, L.d.cout_pad, st);
+    switch (L.tile) {
+        case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
+        case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
+        case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
+        default: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+    }
 }
 
 }  // namespace
@@ -377,11 +393,13 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     e = hipMemset(h->arena, 0, 256 + 2 * in_plane);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                conv_lds_bytes<128, 256>());
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<64, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                conv_lds_bytes<64, 256>());
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile1::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
     *out = h;
     return 0;
@@ -428,6 +446,21 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamm
     MPX_HIP(h, hipMemcpy(L.shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     L.loaded = true;
     return 0;
+}
+
+int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
+    if (!h) return MPX_E_ARG;
+    if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
+    ConvLayer& L = h->convs[i];
+    if (tile < 0) tile = default_tile(L.d);
+    if (tile >= CONV_NUM_TILES) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    L.tile = tile;
+    return 0;
+}
+
+int mpx_get_conv_tile(const mpx_engine* h, int i) {
+    if (!h || i < 0 || i >= (int)h->convs.size()) return MPX_E_ARG;
+    return h->convs[i].tile;
 }
 
 int mpx_weights_complete(const mpx_engine* h) {

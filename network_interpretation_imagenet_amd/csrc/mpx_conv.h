@@ -5,16 +5,21 @@
 // operands, fp32 accumulation).  A = weights (MFMA rows = cout), B = pixels (MFMA cols), so an
 // accumulator register quad is 4 consecutive channels of one pixel.
 //
-// Workgroup = 8 waves (2 cout x 4 pixel), tile TC(cout) x TP(pixel), K advances 32 per step.
-// LDS: a ring of NS = 3 stages, each [W_hi TCx64B][W_lo TCx64B][X_hi TPx64B][X_lo TPx64B], filled by
+// Workgroup = NWR x NWC waves (cout x pixel), tile TC(cout) x TP(pixel), K advances 32 per step.
+// LDS: a ring of NS stages, each [W_hi TCx64B][W_lo TCx64B][X_hi TPx64B][X_lo TPx64B], filled by
 // global_load_lds_dwordx4 in 1-KiB pieces (16 rows x 64 B, lane-linear destination) and consumed behind
 // a COUNTED s_waitcnt vmcnt + one raw s_barrier per K step; fragments are double-buffered in registers
-// (read step k+1 while the MFMAs of step k run), so two DMA stages stay in flight under the MFMAs (cdna_hip_programming.md 5, "Pipelining across barriers").
+// (read step k+1 while the MFMAs of step k run), so NS-1 DMA stages stay in flight under the MFMAs
+// (cdna_hip_programming.md 5, "Pipelining across barriers").
 // Rows are 64 B, which makes a ds_read_b128 fragment read 2-way bank conflicted; the 16-B chunk index
 // is XORed with ((row>>3)&1)<<1 on the DMA's SOURCE address and on the fragment read (rule 21).
 // Epilogue: accumulators -> fp32 tile in LDS (XOR-swizzled 16-B chunks) -> each thread owns 8
 // consecutive channels of one pixel: residual planes are read and output planes written as whole
 // 128-B lines (16 B per lane, 16 or 8 lanes per pixel row).
+//
+// Variants (ConvCfg): 128x256 / 64x256 with 8 waves and a 3-stage ring (one workgroup per CU; fewest bytes
+// per FLOP) and 128x128 / 64x128 with 4 waves and a 2-stage ring (two or three workgroups per CU: the
+// HBM-bound epilogue of one overlaps the MFMA-bound K loop of the other, and small layers get more tiles).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,44 +64,44 @@ struct ConvParams {
     int relu;
 };
 
-constexpr int CONV_THREADS = 512;
-constexpr int CONV_STAGES = 3;
-
-template <int TC, int TP>
-constexpr int conv_lds_bytes() {
-    constexpr int ring = CONV_STAGES * (TC + TP) * 128;
-    constexpr int epi = TP * TC * 4;
-    return ring > epi ? ring : epi;
-}
+template <int TC_, int TP_, int NWR_, int NWC_, int NS_>
+struct ConvCfg {
+    static constexpr int TC = TC_, TP = TP_, NWR = NWR_, NWC = NWC_, NS = NS_;
+    static constexpr int NW = NWR * NWC, NT = 64 * NW;
+    static constexpr int CF = TC / NWR / 16;        // 16-row cout fragments per wave
+    static constexpr int PF = TP / NWC / 16;        // 16-col pixel fragments per wave
+    static constexpr int STAGE = (TC + TP) * 128;
+    static constexpr int WP = TC / 16, XP = TP / 16;            // 1-KiB pieces per plane
+    static constexpr bool HALF_W = (2 * WP == NW);              // waves [0,NW/2) move W_hi, the rest W_lo
+    static constexpr int WJ = HALF_W ? 1 : WP / NW;             // W pieces per wave per plane
+    static constexpr int XJ = XP / NW;                          // X pieces per wave per plane
+    static constexpr int LPT = (HALF_W ? 1 : 2 * WJ) + 2 * XJ;  // DMA instructions per wave per stage
+    static constexpr int EPI = TP * TC * 4;
+    static constexpr int LDS = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static_assert(HALF_W || WP % NW == 0, "W pieces must divide over the waves");
+    static_assert(XP % NW == 0, "X pieces must divide over the waves");
+    static_assert((TC / NWR) % 16 == 0 && (TP / NWC) % 16 == 0 && NS >= 2, "tile shape");
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 5 || N == 6 || N == 10 || N == 12, "add the literal below");
     // lgkmcnt(0): this wave's fragment reads of the previous step have returned before it enters the
     // barrier that frees their ring slot for the next DMA
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int TC, int TP>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvParams p) {
-    static_assert((TC == 128 || TC == 64) && TP == 256, "tile shapes wired below");
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = CONV_STAGES;
-    constexpr int CF = TC / 32;                 // 16-row cout fragments per wave (wave tile TC/2 x TP/4)
-    constexpr int PF = TP / 64;                 // 16-col pixel fragments per wave
+    constexpr int TC = C::TC, TP = C::TP, NS = C::NS, NW = C::NW, NT = C::NT;
+    constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, XJ = C::XJ, LPT = C::LPT, STAGE = C::STAGE;
     constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = TC * 128, OFF_XLO = TC * 128 + TP * 64;
-    constexpr int STAGE = (TC + TP) * 128;
-    constexpr int WPIECES = TC / 16;            // 1-KiB pieces per W plane
-    constexpr int LPT = (2 * WPIECES + 2 * (TP / 16)) / 8;   // DMA instructions per wave per stage (6 or 5)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / C::NWC, wc = wave % C::NWC;
 
     // XCD-aware bijective remap: blocks that share an XCD (b % 8) walk a contiguous range of
     // logical tiles, cout tiles fastest, so the X tile of one pixel range stays in that XCD's L2.
@@ -110,62 +115,81 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
     const int nt = L - mt * p.n_tiles_c;
     const int m0 = mt * TP, n0 = nt * TC;
 
-    // ---- per-thread DMA bookkeeping: lane i of a piece moves row (i>>2), LDS chunk (i&3) ----
-    const int prow = lane >> 2;                                   // row within a 16-row piece
+    // ---- DMA addressing: buffer_load ... lds with wave-uniform descriptors -------------------------------
+    // X descriptors start at the first image this tile touches, so a lane's byte offset is small (a few
+    // images); W descriptors start at the tile's first cout row and the K step is the SGPR soffset.  Per step a
+    // lane spends ~5 VALU per X piece (tap bounds test, one add, one select to the out-of-range offset that
+    // makes the buffer unit return zeros) and none per W piece.
+    const int prow = lane >> 2;                                      // row within a 16-row piece
     const int src_q = ((lane & 3) ^ (((prow >> 3) & 1) << 1)) * 8;   // swizzled source chunk, in elements
-    int x_pixbase[2], x_iy0[2], x_ix0[2];
     const int howo = p.ho * p.wo;
+    const int n_first = m0 / howo;
+    const int img_elems = p.hin * p.win * p.pix_stride;
+    constexpr unsigned OOB = 0x80000000u;                            // >= num_records of every descriptor
+    __amdgpu_buffer_rsrc_t x_rs_hi, x_rs_lo, w_rs_hi, w_rs_lo;
+    {
+        const int n_img = p.M / howo;
+        const size_t rem = (size_t)(n_img - n_first) * img_elems * 2;
+        const int nrec = rem > 0x7fffffffu ? 0x7fffffff : (int)rem;
+        x_rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x_hi + (size_t)n_first * img_elems), 0, nrec, 0x00020000);
+        x_rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x_lo + (size_t)n_first * img_elems), 0, nrec, 0x00020000);
+        const int wrec = TC * p.ktot * 2;
+        w_rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_hi + (size_t)n0 * p.ktot), 0, wrec, 0x00020000);
+        w_rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_lo + (size_t)n0 * p.ktot), 0, wrec, 0x00020000);
+    }
+    int x_off0[XJ], x_iy0[XJ], x_ix0[XJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (i * 8 + wave) * 16 + prow;
+    for (int i = 0; i < XJ; ++i) {
+        const int m = m0 + (i * NW + wave) * 16 + prow;
         const int n = m / howo;
         const int rem = m - n * howo;
         const int oy = rem / p.wo;
         const int ox = rem - oy * p.wo;
-        x_pixbase[i] = n * p.hin * p.win;
         x_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
         x_ix0[i] = ox * p.stride - p.pad;
+        x_off0[i] = (((n - n_first) * p.hin + x_iy0[i]) * p.win + x_ix0[i]) * p.pix_stride * 2 + src_q * 2;
     }
-    // W: TC=128 -> this wave moves piece `wave` of both planes; TC=64 -> waves 0-3 W_hi, 4-7 W_lo
-    const half_t* w_src;
-    const half_t* w_src2 = nullptr;
-    {
-        const int wrow = (TC == 128 ? wave : (wave & 3)) * 16 + prow;
-        const size_t o = (size_t)(n0 + wrow) * p.ktot + src_q;
-        if (TC == 128) {
-            w_src = p.w_hi + o;
-            w_src2 = p.w_lo + o;
-        } else {
-            w_src = (wave < 4 ? p.w_hi : p.w_lo) + o;
-        }
+    // W rows of this wave: piece (j*NW + wave) of each plane; HALF_W: one piece of one plane
+    int w_off[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int piece = C::HALF_W ? (wave % (NW / 2)) : (j * NW + wave);
+        w_off[j] = (piece * 16 + prow) * p.ktot * 2 + src_q * 2;
     }
 
-    // `live` = false issues the same DMAs from the zero page (a step past the end of K): the ring and the
-    // vmcnt bookkeeping then never change shape, so the K loop has no conditional code in it.
-    auto stage_w = [&](int buf, int ks, bool live) {
+    // `live` = false (a step past the end of K) keeps the ring and the vmcnt bookkeeping in shape: the X pieces
+    // read out of range (zeros), the W pieces read whatever follows the row (never used).
+    auto stage_w = [&](int buf, int ks) {
         char* sb = smem + buf * STAGE;
-        if (TC == 128) {
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(live ? w_src + ks * 32 : p.zero_page), MPX_LDS_PTR(sb + OFF_WHI + wave * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(live ? w_src2 + ks * 32 : p.zero_page), MPX_LDS_PTR(sb + OFF_WLO + wave * 1024), 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(live ? w_src + ks * 32 : p.zero_page), MPX_LDS_PTR(sb + wave * 1024), 16, 0, 0);
+        const int soff = ks * 64;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            if (C::HALF_W) {
+                if (wave < NW / 2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j], soff, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j], soff, 0, 0);
+            } else {
+                const int d = (j * NW + wave) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j], soff, 0, 0);
+            }
         }
     };
     auto stage_x = [&](int i, int buf, int ky, int kx, int c0, bool live) {
         char* sb = smem + buf * STAGE;
         const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
         const bool ok = live & ((unsigned)iy < (unsigned)p.hin) & ((unsigned)ix < (unsigned)p.win);   // no short-circuit branches
-        const size_t o = (size_t)(x_pixbase[i] + iy * p.win + ix) * p.pix_stride + c0 + src_q;
-        const half_t* s_hi = ok ? p.x_hi + o : p.zero_page;
-        const half_t* s_lo = ok ? p.x_lo + o : p.zero_page;
-        const int d = (i * 8 + wave) * 1024;
-        __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(s_hi), MPX_LDS_PTR(sb + OFF_XHI + d), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(MPX_GLOBAL_PTR(s_lo), MPX_LDS_PTR(sb + OFF_XLO + d), 16, 0, 0);
+        const int delta = ((ky * p.win + kx) * p.pix_stride + c0) * 2;      // wave-uniform
+        const int voff = ok ? x_off0[i] + delta : (int)OOB;
+        const int d = (i * NW + wave) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb + OFF_XHI + d), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sb + OFF_XLO + d), 16, voff, 0, 0, 0);
     };
     auto stage = [&](int buf, int ks, int ky, int kx, int c0, bool live) {
-        stage_w(buf, ks, live);
-        stage_x(0, buf, ky, kx, c0, live);
-        stage_x(1, buf, ky, kx, c0, live);
+        stage_w(buf, ks);
+#pragma unroll
+        for (int i = 0; i < XJ; ++i) stage_x(i, buf, ky, kx, c0, live);
     };
 
     f4 acc[CF][PF];
@@ -188,8 +212,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
 
     const int lrow = lane & 15;
     const int qsw = ((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16;
-    const int a_off = (wr * (TC / 2) + lrow) * 64 + qsw;
-    const int b_off = (wc * (TP / 4) + lrow) * 64 + qsw;
+    const int a_off = (wr * (TC / C::NWR) + lrow) * 64 + qsw;
+    const int b_off = (wc * (TP / C::NWC) + lrow) * 64 + qsw;
 
     struct Frags {
         h8 a_hi[CF], a_lo[CF], b_hi[PF], b_lo[PF];
@@ -207,6 +231,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
             f.b_lo[b] = *(const h8*)(sb + OFF_XLO + b_off + b * 1024);
         }
     };
+    constexpr int NF = 2 * (CF + PF);                   // fragment reads per step
+    constexpr int NM = 3 * CF * PF;                     // MFMAs per step
+    auto load_frag = [&](int slot, Frags& f, int j) {   // fragment j of step: a_hi[..] a_lo[..] b_hi[..] b_lo[..]
+        const char* sb = smem + slot * STAGE;
+        if (j < CF) f.a_hi[j] = *(const h8*)(sb + OFF_WHI + a_off + j * 1024);
+        else if (j < 2 * CF) f.a_lo[j - CF] = *(const h8*)(sb + OFF_WLO + a_off + (j - CF) * 1024);
+        else if (j < 2 * CF + PF) f.b_hi[j - 2 * CF] = *(const h8*)(sb + OFF_XHI + b_off + (j - 2 * CF) * 1024);
+        else f.b_lo[j - 2 * CF - PF] = *(const h8*)(sb + OFF_XLO + b_off + (j - 2 * CF - PF) * 1024);
+    };
+    auto mfma_one = [&](const Frags& f, int i) {        // flat order (a, term, b): neighbours hit different accumulators
+        const int a = i / (3 * PF), r = i % (3 * PF), term = r / PF, b = r % PF;
+        if (term == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a_hi[a], f.b_lo[b], acc[a][b], 0, 0, 0);
+        else if (term == 1) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a_lo[a], f.b_hi[b], acc[a][b], 0, 0, 0);
+        else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a_hi[a], f.b_hi[b], acc[a][b], 0, 0, 0);
+    };
     auto mfma_row = [&](const Frags& f, int a) {        // PF*3 MFMAs: one 16-channel row of fragments
 #pragma unroll
         for (int b = 0; b < PF; ++b) {
@@ -220,57 +259,53 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
         for (int a = 0; a < CF; ++a) mfma_row(f, a);
     };
 
-    // Pipeline: the fragment registers are a 4th stage.  While the MFMAs of step ks run from registers,
-    // the fragments of step ks+1 are read from the ring and the DMAs of steps ks+2, ks+3 are in flight.
+    // Pipeline: the fragment registers are one more stage.  While the MFMAs of step ks run from registers,
+    // the fragments of step ks+1 are read from the ring and the DMAs of steps ks+2 .. ks+NS are in flight.
     // prologue: stages 0..NS-1 issued (dummies past the end of K), fragments of step 0 in registers
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         stage(s, s, ky, kx, c0, s < nk);
         advance();
     }
-    wait_vmcnt<2 * LPT>();
+    wait_vmcnt<(NS - 1) * LPT>();
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;
     load_frags(0, fa);
 
     int slot = 0;                   // ring slot of step ks
-    // a step that has a successor: frags of ks are in `cur`; leaves frags of ks+1 in `nxt`.  Branch-free.
-    // The issue order inside a step is pinned with sched_barrier(0) fences (hipcc otherwise clumps the DMA
-    // address arithmetic ahead of the MFMAs and the fragment reads behind them, which exposes both):
-    //   the MFMAs of step ks in rows of PF*3; after row 0 the fragment reads of step ks+1 (their LDS latency
-    //   hides under the later rows) and between rows one piece of the DMA issue for step ks+3 -- while this wave
-    //   does address arithmetic, its SIMD partner (waves w and w+4 share a SIMD) has the matrix pipe.
+    // A step that has a successor: frags of ks are in `cur`; leaves frags of ks+1 in `nxt`.  Branch-free, and
+    // hand-scheduled: every instruction sits between sched_barrier(0) fences, because the waves of a workgroup
+    // leave the barrier in lockstep and an in-order wave that meets a burst (16 fragment reads from 8 waves at
+    // once, or a clump of DMA address arithmetic) cannot issue MFMAs behind it.  The order per step is
+    //   MFMA 0 (hipcc guards its operands with an lgkmcnt(0) that finds nothing outstanding here),
+    //   then one fragment read of step ks+1 after every second MFMA,
+    //   then the 1+XJ DMA groups of step ks+NS spread evenly over the remaining MFMAs.
     auto full_step = [&](int ks, const Frags& cur, Frags& nxt) {
-        // own pieces of stage ks+1 landed (stage ks+2 stays in flight), and -- lgkmcnt(0) -- this wave's
-        // reads of slot(ks) returned; the barrier then frees slot(ks) for stage ks+3
+        // own pieces of stage ks+1 landed (younger stages stay in flight), and -- lgkmcnt(0) -- this wave's
+        // reads of slot(ks) returned; the barrier then frees slot(ks) for stage ks+NS
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<LPT>();
+        wait_vmcnt<(NS - 2) * LPT>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
         const bool live = ks + NS < nk;
-        // row 0 first: hipcc cannot see the inline-asm wait above and guards the first use of `cur` with its
-        // own lgkmcnt(0); placed here it finds nothing outstanding (behind the reads it would wait for them)
-        mfma_row(cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(nslot, nxt);
-        stage_w(slot, ks + NS, live);
-        if (CF == 2) {
-            stage_x(0, slot, ky, kx, c0, live);
-            stage_x(1, slot, ky, kx, c0, live);
+        constexpr int G = 1 + XJ;                       // DMA groups: W, X piece 0, X piece 1, ...
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            mfma_one(cur, i);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_row(cur, 1);
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_x(0, slot, ky, kx, c0, live);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(cur, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_x(1, slot, ky, kx, c0, live);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(cur, CF - 1);
+            if ((i & 1) == 0 && i / 2 < NF) {
+                load_frag(nslot, nxt, i / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (i == (((2 * g + 1) * NM) / (2 * G) | 1)) {
+                    if (g == 0) stage_w(slot, ks + NS);
+                    else stage_x(g - 1, slot, ky, kx, c0, live);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         advance();
         slot = nslot;
@@ -291,7 +326,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
     // ---- epilogue ----
     // Phase 0: prefetch the residual rows this thread will own in phase 2 (whole 16-B chunks).
     constexpr int GPP = TC / 8;                 // threads per pixel row (8 channels each)
-    constexpr int PPI = CONV_THREADS / GPP;     // pixels per phase-2 iteration
+    constexpr int PPI = NT / GPP;               // pixels per phase-2 iteration
     constexpr int ITERS = TP / PPI;
     constexpr int RP = TC * 4;                  // fp32 tile row pitch in bytes
     const int g = tid % GPP;
@@ -314,12 +349,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
     // Phase 1: acc*scale+shift -> fp32 tile [pixel][cout] in LDS; D row = cout (lane>>4)*4+reg, col = pixel.
 #pragma unroll
     for (int a = 0; a < CF; ++a) {
-        const int col = wr * (TC / 2) + a * 16 + (lane >> 4) * 4;       // cout within the tile
+        const int col = wr * (TC / C::NWR) + a * 16 + (lane >> 4) * 4;     // cout within the tile
         const f4 sc = *(const f4*)(p.scale + n0 + col);
         const f4 sh = *(const f4*)(p.shift + n0 + col);
 #pragma unroll
         for (int b = 0; b < PF; ++b) {
-            const int pl = wc * (TP / 4) + b * 16 + lrow;               // pixel within the tile
+            const int pl = wc * (TP / C::NWC) + b * 16 + lrow;              // pixel within the tile
             const f4 v = acc[a][b] * sc + sh;
             *(f4*)(smem + pl * RP + (((col >> 2) ^ (pl & 7)) << 4)) = v;
         }
@@ -359,6 +394,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_f16x3_kernel(const ConvP
             *(h8*)(p.y_lo + o) = ol;
         }
     }
+#endif
 }
+
+// Tile variants selectable per layer (mpx_set_conv_tile).
+typedef ConvCfg<128, 256, 2, 4, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
+typedef ConvCfg<64, 256, 2, 4, 3> ConvTile1;    // cout <= 64
+typedef ConvCfg<128, 128, 2, 2, 2> ConvTile2;   // 4 waves, 64 KB LDS, 2 workgroups / CU
+typedef ConvCfg<64, 128, 2, 2, 2> ConvTile3;    // cout <= 64, 48 KB LDS, 3 workgroups / CU
+constexpr int CONV_NUM_TILES = 4;
 
 }  // namespace mpx

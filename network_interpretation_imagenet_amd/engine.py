@@ -243,6 +243,16 @@ class MaskedForwardEngine:
         p = np.exp(z - z.max())
         return int(pred[0]), (p / p.sum()).astype(np.float32)
 
+    # ---- kernel variants (tuning / tests) ----
+    def set_conv_tile(self, layer, tile):
+        """Select the conv kernel variant of one layer (index or torchvision name); tile < 0 = default."""
+        i = layer if isinstance(layer, int) else [d.name.decode() for d in self.layers].index(layer)
+        _lib.check(self._h, self._lib.mpx_set_conv_tile(self._h, int(i), int(tile)), "mpx_set_conv_tile")
+
+    def conv_tile(self, layer):
+        i = layer if isinstance(layer, int) else [d.name.decode() for d in self.layers].index(layer)
+        return int(self._lib.mpx_get_conv_tile(self._h, int(i)))
+
     # ---- profiling ----
     def profile(self, on=True):
         _lib.check(self._h, self._lib.mpx_profile_enable(self._h, 1 if on else 0), "mpx_profile_enable")

@@ -161,9 +161,17 @@ R101_LAYERS = ["layer1.0.conv1", "layer1.0.conv2", "layer1.0.conv3", "layer1.0.d
                "layer4.0.conv2", "layer4.2.conv3"]
 
 
-def _check_layer(eng, sd, name, batch=3):
+def _check_layer(eng, sd, name, batch=3, tile=-1):
     i = _layer_index(eng, name)
     d = eng.layers[i]
+    eng.set_conv_tile(i, tile)
+    try:
+        _check_layer_body(eng, sd, i, d, name, batch)
+    finally:
+        eng.set_conv_tile(i, -1)
+
+
+def _check_layer_body(eng, sd, i, d, name, batch):
     g = torch.Generator().manual_seed(i)
     x = torch.randn(batch, d.hin, d.hin, d.cin, generator=g).clamp_min(-0.5) * 1.5     # mostly post-ReLU-like
     res = torch.randn(batch, d.hout, d.hout, d.cout, generator=g) if d.residual else None
@@ -185,6 +193,24 @@ def test_conv_layers_resnet18(eng18, name):
 @pytest.mark.parametrize("name", R101_LAYERS)
 def test_conv_layers_resnet101(eng101, name):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv3", "layer2.0.conv2", "layer3.5.conv2", "layer4.2.conv3"])
+def test_conv_every_tile_variant(eng101, name, tile):
+    """Each kernel variant (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
+
+
+def test_set_conv_tile_errors(eng18):
+    assert eng18._lib.mpx_set_conv_tile(eng18._h, 999, 0) == -1
+    assert eng18._lib.mpx_set_conv_tile(eng18._h, 1, 17) == -1
+    assert eng18._lib.mpx_get_conv_tile(eng18._h, 999) == -1
+    default = eng18.conv_tile(1)
+    eng18.set_conv_tile(1, 3)
+    assert eng18.conv_tile(1) == 3
+    eng18.set_conv_tile(1, -1)
+    assert eng18.conv_tile(1) == default
 
 
 def test_stem_conv_from_staged_input(eng18, dev):
@@ -332,6 +358,37 @@ def test_properties_full_batch(eng18):
     assert (lg0.argmax(1) == p0).all()
     _o, s_again, _ = eng18.score_masks(imgs[0], seg, onoff, label)
     assert (s_again == s0).all()                            # deterministic run to run
+
+
+def test_resnet101_full_batch_properties(mpx_lib, dev):
+    """BASELINE configs[2] batch shape (ResNet-101, 512 masks of one image in one forward batch): the oracle
+    cannot cover this size on the CPU, so check size-independent properties instead."""
+    eng = MaskedForwardEngine("resnet101", max_batch=512, device=0).load_state_dict(synth.make_state_dict("resnet101"))
+    try:
+        imgs = synth.make_images(2, seed=21, kind="noise")
+        seg = synth.grid_segments()
+        onoff = synth.random_onoff(512, 196, seed=3)
+        onoff[0] = 1
+        onoff[1] = 0
+        onoff[511] = onoff[7]
+        onoff[300] = onoff[7]
+        base_pred, base_prob = eng.predict(imgs[0])
+        _o, s0, p0, lg = eng.score_masks(imgs[0], seg, onoff, base_pred, return_logits=True)
+        _o, s1, _p = eng.score_masks(imgs[1], seg, onoff, base_pred)
+        assert abs(s0[0] - base_prob[base_pred]) < 1e-6 and p0[0] == base_pred     # all-ones == unmasked
+        assert s0[1] == s1[1]                                                      # all-zeros: image-independent
+        assert s0[7] == s0[300] == s0[511]                                         # slot invariance, bit for bit
+        assert np.isfinite(lg).all() and (lg.argmax(1) == p0).all()
+        sm = np.exp(lg - lg.max(1, keepdims=True))
+        sm /= sm.sum(1, keepdims=True)
+        assert np.abs(sm[np.arange(512), base_pred] - s0).max() < 1e-6
+        # the same masks through a smaller engine (different batch -> different tile rounds) agree bit for bit
+        small = MaskedForwardEngine("resnet101", max_batch=24, device=0).load_state_dict(synth.make_state_dict("resnet101"))
+        _o, s_small, p_small = small.score_masks(imgs[0], seg, onoff[:48], base_pred)
+        small.close()
+        assert (s_small == s0[:48]).all() and (p_small == p0[:48]).all()
+    finally:
+        eng.close()
 
 
 def test_engine_errors(eng18, dev):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time ONE conv layer through the C-ABI (mpx_conv_bn_act) with random split-fp16 planes.
-usage: python tools/conv_bench.py [arch] [layer-name] [batch] [reps]"""
+usage: python tools/conv_bench.py [arch] [layer-name] [batch] [reps] [tile,...]"""
 import ctypes as C
 import os
 import sys
@@ -31,7 +31,18 @@ def planes(*shape):
     return hi, (x - hi.float()).half()
 
 
-xh, xl = planes(batch, d.hin, d.hin, d.cin)
+stem = (i == 0)
+eng2 = None
+if stem:       # the stem reads the engine's own padded staging: fill it through K0 and use a matching engine
+    eng.close()
+    eng = MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(synth.make_state_dict(arch))
+    img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
+    seg = torch.from_numpy(synth.grid_segments()).to(dev)
+    onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
+    eng.stage_masks(img, seg, onoff, 0)
+    xh = xl = None
+else:
+    xh, xl = planes(batch, d.hin, d.hin, d.cin)
 rh, rl = planes(batch, d.hout, d.hout, d.cout) if d.residual else (None, None)
 oh = torch.empty(batch, d.hout, d.hout, d.cout, dtype=torch.float16, device=dev)
 ol = torch.empty_like(oh)
@@ -42,16 +53,19 @@ def run():
     _lib.check(eng._h, eng._lib.mpx_conv_bn_act(eng._h, i, p(xh), p(xl), p(rh), p(rl), p(oh), p(ol), None, batch, None), "conv")
 
 
-for _ in range(3):
-    run()
-torch.cuda.synchronize()
-t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-t0.record()
-for _ in range(reps):
-    run()
-t1.record()
-torch.cuda.synchronize()
-ms = t0.elapsed_time(t1) / reps
+tiles = [int(t) for t in sys.argv[5].split(",")] if len(sys.argv) > 5 else [-1]
 fl = 2.0 * batch * d.hout * d.hout * d.cout * d.cin * d.ksize * d.ksize
-print("%s %s B=%d: %d->%d k%d s%d out%d  %.4f ms  %.1f TFLOP/s algorithmic (x3 issued = %.0f)" % (
-    arch, layer, batch, d.cin, d.cout, d.ksize, d.stride, d.hout, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
+for tile in tiles:
+    eng.set_conv_tile(i, tile)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        run()
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / reps
+    print("%s %s B=%d tile=%d: %d->%d k%d s%d out%d res=%d  %.4f ms  %.1f TFLOP/s algorithmic (x3 issued = %.0f)" % (
+        arch, layer, batch, eng.conv_tile(i), d.cin, d.cout, d.ksize, d.stride, d.hout, d.residual, ms, fl / ms / 1e9, 3 * fl / ms / 1e9))
