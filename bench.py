@@ -41,6 +41,9 @@ def parse():
                     help="images whose masks share one forward batch (batch = this x masks; larger batches fill "
                          "256 CUs with fewer partial rounds of tiles)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent forward batches in flight (one engine + HIP stream each): lets the HBM-bound "
+                         "kernels of one batch overlap the MFMA-bound kernels of another")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
     return ap.parse_args()
@@ -88,8 +91,11 @@ def main():
     if n_img % ipf:
         raise SystemExit("--images must be a multiple of --images-per-forward")
     batch = ipf * n_mask
-    eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank)
-    eng.load_state_dict(synth.make_state_dict(args.arch))
+    sd = synth.make_state_dict(args.arch)
+    engines = [MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank).load_state_dict(sd)
+               for _ in range(max(1, args.streams))]
+    streams = [torch.cuda.Stream(device=dev) for _ in engines]
+    eng = engines[0]
     # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
     # per-image Bernoulli(0.4) mask-vectors, labels = unmasked argmax (the reference's correctness gate)
     imgs = torch.from_numpy(synth.make_images(n_img, seed=1234 + rank, kind="noise")).to(dev)
@@ -109,16 +115,22 @@ def main():
     total = world * n_img * n_mask
 
     def step(profile):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
         for f, i0 in enumerate(range(0, n_img, ipf)):
-            prof = profile and (f % PROFILE_EVERY == 0)
-            if prof:
-                eng.profile(True)
-            for j in range(ipf):
-                eng.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
-            s, _p = eng.forward(batch, label_rows[i0:i0 + ipf].view(-1))
-            scores[i0:i0 + ipf] = s.view(ipf, n_mask)
-            if prof:
-                eng.profile(False)
+            e, st = engines[f % len(engines)], streams[f % len(engines)]
+            prof = profile and (f % PROFILE_EVERY == 0) and e is eng
+            with torch.cuda.stream(st):
+                if prof:
+                    e.profile(True)
+                for j in range(ipf):
+                    e.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
+                s, _p = e.forward(batch, label_rows[i0:i0 + ipf].view(-1))
+                scores[i0:i0 + ipf] = s.view(ipf, n_mask)
+                if prof:
+                    e.profile(False)
+        for st in streams:
+            torch.cuda.current_stream(dev).wait_stream(st)
         if use_dist:
             return shard.all_gather_blocks(scores.view(-1), total)
         return scores.view(-1)
@@ -171,14 +183,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (BASELINE configs[2]; x%d GPUs)" % (args.arch, n_mask, n_img, world),
-                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch,
+                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "streams": len(engines),
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline(args.arch, args.cpu_masks) if (world == 1 and args.cpu_masks > 0) else None,
         }
         print(json.dumps(line))
-    eng.close()
+    for e in engines:
+        e.close()
     if use_dist:
         dist.destroy_process_group()
 
