@@ -49,6 +49,18 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(arch, batch):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
+    from inside the process); None unless a profile of this arch and forward batch exists."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        with open(path) as fh:
+            j = json.load(fh)
+        if j.get("forward_batch") == batch and arch == j.get("arch", "resnet101"):
+            return j["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(arch, n_masks):
     """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per
     superpixel) on this box's host cores, bounded sample of the same workload."""
@@ -171,7 +183,7 @@ def main():
             # of the launches / their summed HIP-event durations; MFMA-issued FLOPs are 3x algorithmic.
             achieved = flops_per_batch * batches_profiled / (conv_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                        "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(args.arch, batch),
                         "kernel": "conv_f16x3_kernel", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,

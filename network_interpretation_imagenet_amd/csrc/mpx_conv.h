@@ -399,7 +399,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
 
 // Tile variants selectable per layer (mpx_set_conv_tile).
 typedef ConvCfg<128, 256, 2, 4, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
-typedef ConvCfg<64, 256, 2, 4, 3> ConvTile1;    // cout <= 64
+typedef ConvCfg<64, 256, 1, 4, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
 typedef ConvCfg<128, 128, 2, 2, 2> ConvTile2;   // 4 waves, 64 KB LDS, 2 workgroups / CU
 typedef ConvCfg<64, 128, 2, 2, 2> ConvTile3;    // cout <= 64, 48 KB LDS, 3 workgroups / CU
 constexpr int CONV_NUM_TILES = 4;
