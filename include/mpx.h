@@ -143,6 +143,16 @@ int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* l
 int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred,
                 float* logits_out, int B, void* stream);
 
+/* ---- K5: heat-map accumulation ---------------------------------------------
+ * replaces: summed_superpixel_labels[segments == v] += 1 for every selected superpixel of a correctly
+ *           predicted mask (gp_superpixel_data_imagenet.py:322-323) and the pure-Python read-back loops of
+ *           gp_regression.py:82-94:  heat[p] += sum_m [pred[m] == label[m]] * onoff[m][seg[p]].
+ * seg DEV i32[224][224] ranks, onoff DEV u8[M][S], pred/label DEV i32[M], heat DEV f32[224][224] (accumulated
+ * in place: zero it first; with several GPUs all-reduce it afterwards).  Uses a small engine-owned scratch
+ * (S <= 4096). */
+int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* onoff, const int32_t* pred,
+                           const int32_t* label, int M, int S, float* heat, void* stream);
+
 /* ---- introspection for tests / benchmarks --------------------------------------------------- */
 /* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4]. */
 int mpx_input_planes(const mpx_engine* h, void** hi, void** lo);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mpx_global_avgpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mpx_head_softmax_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_heatmap_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mpx_input_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mpx_profile_enable": (_i, [_vp, _i]),
     "mpx_profile_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

@@ -68,6 +68,7 @@ struct mpx_engine {
     half_t* pool_lo = nullptr;
     float* logits = nullptr;
     half_t* zero_page = nullptr;
+    float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
     bool prof_on = false;
     std::vector<ProfRec> prof_pool;
@@ -365,13 +366,15 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     size_t wbytes = 0;
     for (const ConvLayer& L : h->convs)
         wbytes += 2 * round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
-    const size_t total = 256 + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
+    const size_t scratch_bytes = 4096 * sizeof(float);
+    const size_t total = 256 + scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
     h->arena_bytes = total;
     char* cur = h->arena;
     auto take = [&](size_t n) { char* r = cur; cur += n; return r; };
     h->zero_page = (half_t*)take(256);
+    h->seg_scratch = (float*)take(scratch_bytes);
     h->in_hi = (half_t*)take(in_plane);
     h->in_lo = (half_t*)take(in_plane);
     for (int b = 0; b < kActBufs; ++b) {
@@ -390,7 +393,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         L.shift = (float*)take(sb);
     }
     // zero page and the never-written borders of the input staging must be zero
-    e = hipMemset(h->arena, 0, 256 + 2 * in_plane);
+    e = hipMemset(h->arena, 0, 256 + scratch_bytes + 2 * in_plane);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
@@ -587,6 +590,22 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
         }
         if (rc) return rc;
     }
+    return 0;
+}
+
+int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* onoff, const int32_t* pred,
+                           const int32_t* label, int M, int S, float* heat, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!seg || !onoff || !pred || !label || !heat || M <= 0 || S <= 0 || S > 4096)
+        return fail(h, MPX_E_ARG, "heatmap_accumulate: null pointer, empty M/S or S > 4096");
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(heatmap_segment_count_kernel, dim3((S + 255) / 256), dim3(256), 0, st, onoff, pred, label, M, S,
+                       h->seg_scratch);
+    MPX_HIP(h, hipGetLastError());
+    const int npix = MPX_IMG * MPX_IMG;
+    hipLaunchKernelGGL(heatmap_gather_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, seg, h->seg_scratch, S, npix, heat);
+    MPX_HIP(h, hipGetLastError());
     return 0;
 }
 

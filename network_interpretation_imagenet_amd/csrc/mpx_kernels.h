@@ -211,4 +211,29 @@ __global__ __launch_bounds__(256) void head_softmax_gather_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K5: heat-map accumulation  y[p] += sum_m [pred[m] == label[m]] * onoff[m][seg[p]]
+// (gp_superpixel_data_imagenet.py:322-323 / gp_regression.py:82-94).  Two tiny launches: per-superpixel
+// counts (one thread per superpixel, coalesced over s), then a gather over the 50,176 pixels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heatmap_segment_count_kernel(const uint8_t* __restrict__ onoff,
+                                                                    const int32_t* __restrict__ pred,
+                                                                    const int32_t* __restrict__ label, int M, int S,
+                                                                    float* __restrict__ per_segment) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    int count = 0;
+    for (int m = 0; m < M; ++m) count += (pred[m] == label[m] && onoff[(size_t)m * S + s]) ? 1 : 0;
+    per_segment[s] = (float)count;
+}
+
+__global__ __launch_bounds__(256) void heatmap_gather_kernel(const int32_t* __restrict__ seg,
+                                                             const float* __restrict__ per_segment, int S, int npix,
+                                                             float* __restrict__ heat) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int s = seg[p];
+    if ((unsigned)s < (unsigned)S) heat[p] += per_segment[s];
+}
+
 }  // namespace mpx

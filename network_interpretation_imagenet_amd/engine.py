@@ -243,6 +243,22 @@ class MaskedForwardEngine:
         p = np.exp(z - z.max())
         return int(pred[0]), (p / p.sum()).astype(np.float32)
 
+    def heatmap_accumulate(self, seg, onoff, pred, labels, heat):
+        """K5: heat[p] += sum_m [pred[m] == labels[m]] * onoff[m][seg[p]] on the device
+        (gp_superpixel_data_imagenet.py:322-323).  seg i32[224,224], onoff u8[M,S], pred/labels i32[M],
+        heat f32[224,224] -- all device tensors; heat is updated in place."""
+        m, s = onoff.shape
+        for name, t, dt in (("seg", seg, torch.int32), ("onoff", onoff, torch.uint8), ("pred", pred, torch.int32),
+                            ("labels", labels, torch.int32), ("heat", heat, torch.float32)):
+            if t.device != self.device or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous %s tensor on %s" % (name, dt, self.device))
+        if tuple(seg.shape) != (IMG, IMG) or tuple(heat.shape) != (IMG, IMG) or pred.numel() != m or labels.numel() != m:
+            raise ValueError("shapes: seg/heat [224,224], pred/labels [M], onoff [M,S]")
+        _lib.check(self._h, self._lib.mpx_heatmap_accumulate(self._h, _ptr(seg), _ptr(onoff), _ptr(pred), _ptr(labels),
+                                                             int(m), int(s), _ptr(heat), self._stream()),
+                   "mpx_heatmap_accumulate")
+        return heat
+
     # ---- kernel variants (tuning / tests) ----
     def set_conv_tile(self, layer, tile):
         """Select the conv kernel variant of one layer (index or torchvision name); tile < 0 = default."""

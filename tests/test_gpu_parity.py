@@ -391,6 +391,24 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
         eng.close()
 
 
+def test_heatmap_accumulate_exact(eng18, dev, golden_dir):
+    """K5 vs the oracle's literal accumulation (integer-valued, so exact)."""
+    seg = np.load(os.path.join(golden_dir, "segments_blobs.npz"))["segments"][0].astype(np.int32)
+    s = int(seg.max()) + 1
+    onoff = np.concatenate([masks.windows_onoff(s, range(0, s + 1)), synth.random_onoff(30, s, seed=8)])
+    m = onoff.shape[0]
+    rng = np.random.default_rng(0)
+    label = np.full(m, 7, dtype=np.int32)
+    pred = np.where(rng.random(m) < 0.5, 7, 9).astype(np.int32)
+    heat = torch.zeros(224, 224, dtype=torch.float32, device=dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    eng18.heatmap_accumulate(t(seg), t(onoff), t(pred), t(label), heat)
+    eng18.heatmap_accumulate(t(seg), t(onoff), t(pred), t(label), heat)          # accumulates in place
+    want = scorer.summed_superpixel_labels(seg, onoff, pred == label)
+    assert (heat.cpu().numpy().astype(np.float64) == 2 * want).all()
+    assert eng18._lib.mpx_heatmap_accumulate(eng18._h, None, None, None, None, 1, 1, None, None) == -1
+
+
 def test_engine_errors(eng18, dev):
     img = synth.make_images(1)[0]
     seg = synth.grid_segments()

@@ -202,6 +202,22 @@ def test_api_bo_style_caller(coarse_setup):
     assert xp.shape == (5, 1) and yp.shape == (5,) and eng.calls == 1
 
 
+def test_bo_loop_end_to_end(coarse_setup):
+    """BASELINE config 5 plumbing on the CPU: the package's BO loop (same signature as
+    BayesianOptimization.py:99-100) drives api.sample_loss; the engine is asked for scores exactly once."""
+    from network_interpretation_imagenet_amd import bo
+    eng, loader, _seg, _label, _ = coarse_setup
+    ub = masks.bo_upper_bound(16)
+    xp, yp = bo.bayesian_optimisation(n_iters=4, sample_loss=api.sample_loss, val_loader=loader, nn_model=eng,
+                                      criterion=None, bounds=np.array([[0, ub]]), n_pre_samples=3,
+                                      rng=random.Random(1))
+    assert xp.shape == (7, 1) and yp.shape == (7,) and eng.calls == 1
+    assert ((xp >= 0) & (xp <= ub)).all() and np.isfinite(yp).all()
+    table = api._LAST["session"].table()[0]
+    assert all(abs(yp[i] - table[int(xp[i, 0])]) < 1e-7 for i in range(7))
+    assert len({float(v) for v in xp[:, 0]}) >= 4                         # the loop explores, duplicates are re-drawn
+
+
 def test_api_validate_generators(coarse_setup):
     eng, loader, seg, label, mask_dir = coarse_setup
     n_ok = api.validate(loader, eng, None, 2)
