@@ -78,8 +78,8 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamm
 int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has weights */
 
 /* Kernel variant of layer i (tuning / test hook; results are identical up to fp32 summation order):
- * 0 = 128x256 tile, 8 waves, 3-stage LDS ring (1 workgroup per CU); 1 = 64x256 (cout <= 64);
- * 2 = 128x128, 4 waves, 2-stage ring (2 workgroups per CU); 3 = 64x128.  tile < 0 restores the default. */
+ * 0 = 128x256 tile, 8 waves, 3-stage LDS ring (1 workgroup per CU); 1 = 64x256, 4 waves side by side;
+ * 2 = 128x128, 4 waves, 2-stage ring (2 workgroups per CU); 3 = 128x64 (3 per CU).  tile < 0 = default. */
 int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
 int mpx_get_conv_tile(const mpx_engine* h, int i);
 

@@ -340,8 +340,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
             const int pix = m0 + it * PPI + prow2;
             if (co_ok && pix < p.M) {
                 const size_t o = (size_t)pix * p.cout + co8;
-                rh[it] = *(const h8*)(p.r_hi + o);
-                rl[it] = *(const h8*)(p.r_lo + o);
+                rh[it] = __builtin_nontemporal_load((const h8*)(p.r_hi + o));    // streamed once: keep X/W in L2
+                rl[it] = __builtin_nontemporal_load((const h8*)(p.r_lo + o));
             }
         }
     }
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
                 oh[j] = hi;
                 ol[j] = lo;
             }
-            *(h8*)(p.y_hi + o) = oh;
-            *(h8*)(p.y_lo + o) = ol;
+            __builtin_nontemporal_store(oh, (h8*)(p.y_hi + o));
+            __builtin_nontemporal_store(ol, (h8*)(p.y_lo + o));
         }
     }
 #endif
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
 typedef ConvCfg<128, 256, 2, 4, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
 typedef ConvCfg<64, 256, 1, 4, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
 typedef ConvCfg<128, 128, 2, 2, 2> ConvTile2;   // 4 waves, 64 KB LDS, 2 workgroups / CU
-typedef ConvCfg<64, 128, 2, 2, 2> ConvTile3;    // cout <= 64, 48 KB LDS, 3 workgroups / CU
+typedef ConvCfg<128, 64, 2, 2, 2> ConvTile3;    // narrow pixel tile: 48 KB LDS, 3 workgroups / CU (measured slower than tile 2 everywhere)
 constexpr int CONV_NUM_TILES = 4;
 
 }  // namespace mpx

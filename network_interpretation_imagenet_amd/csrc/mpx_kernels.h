@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void mask_apply_normalize_kernel(const MaskPar
         oh[3] = (half_t)0.f;
         ol[3] = (half_t)0.f;
         const size_t so = (size_t)(p.slot0 + m) * plane + pad_off;
-        *(h4*)(p.out_hi + so) = oh;
+        *(h4*)(p.out_hi + so) = oh;       // plain stores: the stem reads these planes next, out of L2 / Infinity Cache
         *(h4*)(p.out_lo + so) = ol;
         if (p.out_f32) {
 #pragma unroll
