@@ -95,6 +95,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
 
     import __graft_entry__ as g
+    if use_dist:            # one builder per node; the others load the finished library
+        if local_rank == 0:
+            g.build()
+        dist.barrier()
     g.build()
     from network_interpretation_imagenet_amd import shard, synth
     from network_interpretation_imagenet_amd.engine import MaskedForwardEngine

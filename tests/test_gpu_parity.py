@@ -334,6 +334,26 @@ def test_resnet18_vs_live_oracle_noise_image(eng18):
     assert (p_u8 == ref_pred).all() and (p_f32 == ref_pred).all()
 
 
+@pytest.mark.parametrize("arch", ["resnet34", "resnet50"])
+def test_other_depths_vs_live_oracle(mpx_lib, arch):
+    """The remaining torchvision ResNet topologies the reference's `-a` flag can name (BasicBlock 3-4-6-3 and
+    Bottleneck 3-4-6-3): 6 masks against the reference-style CPU loop."""
+    sd = synth.make_state_dict(arch)
+    eng = MaskedForwardEngine(arch, max_batch=8, device=0).load_state_dict(sd)
+    try:
+        img = synth.make_images(1, seed=3)[0]
+        x = scorer.to_tensor_normalize(img)
+        seg = synth.grid_segments(block=32)                       # 49 superpixels
+        onoff = np.concatenate([masks.windows_onoff(49, [0, 7, 30]), synth.random_onoff(3, 49, seed=1)])
+        label = scorer.base_prediction(sd, arch, x)
+        assert eng.predict(img)[0] == label
+        ref, ref_pred = scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, label)
+        _o, score, pred = eng.score_masks(img, seg, onoff, label)
+        assert np.abs(score - ref).max() <= SCORE_TOL_TIGHT and (pred == ref_pred).all()
+    finally:
+        eng.close()
+
+
 def test_properties_full_batch(eng18):
     """Size-independent properties at the engine's full batch (64) and beyond it (chunking)."""
     imgs = synth.make_images(2, seed=5, kind="noise")
