@@ -179,9 +179,12 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     auto stage_x = [&](int i, int buf, int ky, int kx, int c0, bool live) {
         char* sb = smem + buf * STAGE;
         const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-        const bool ok = live & ((unsigned)iy < (unsigned)p.hin) & ((unsigned)ix < (unsigned)p.win);   // no short-circuit branches
         const int delta = ((ky * p.win + kx) * p.pix_stride + c0) * 2;      // wave-uniform
-        const int voff = ok ? x_off0[i] + delta : (int)OOB;
+        // Out-of-range taps (and steps past the end of K) set the offset's sign bit, which is >= num_records, so
+        // the buffer unit returns zeros.  Pure bit arithmetic on purpose: hipcc lowers a per-lane `ok ? a : b` to an
+        // s_and_saveexec region, and an MFMA that the scheduler drops into such a region would run with EXEC
+        // partly off and leave those lanes' results unwritten.
+        const int voff = (x_off0[i] + delta) | ((iy | (p.hin - 1 - iy) | ix | (p.win - 1 - ix)) & (int)OOB) | (live ? 0 : (int)OOB);
         const int d = (i * NW + wave) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb + OFF_XHI + d), 16, voff, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sb + OFF_XLO + d), 16, voff, 0, 0, 0);
