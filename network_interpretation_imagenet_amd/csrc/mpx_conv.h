@@ -6,20 +6,20 @@
 // accumulator register quad is 4 consecutive channels of one pixel.
 //
 // Workgroup = NWR x NWC waves (cout x pixel), tile TC(cout) x TP(pixel), K advances 32 per step.
-// LDS: a ring of NS stages, each [W_hi TCx64B][W_lo TCx64B][X_hi TPx64B][X_lo TPx64B], filled by
-// global_load_lds_dwordx4 in 1-KiB pieces (16 rows x 64 B, lane-linear destination) and consumed behind
-// a COUNTED s_waitcnt vmcnt + one raw s_barrier per K step; fragments are double-buffered in registers
-// (read step k+1 while the MFMAs of step k run), so NS-1 DMA stages stay in flight under the MFMAs
-// (cdna_hip_programming.md 5, "Pipelining across barriers").
+// LDS: a ring of NSW stages [W_hi TCx64B][W_lo TCx64B] and a ring of NSX stages [X_hi TPx64B][X_lo TPx64B],
+// filled by buffer_load_dwordx4 ... lds in 1-KiB pieces (16 rows x 64 B, lane-linear destination) and
+// consumed behind a COUNTED s_waitcnt vmcnt + one raw s_barrier per K step; fragments are double-buffered
+// in registers (read step k+1 while the MFMAs of step k run), so the younger DMA stages stay in flight
+// under the MFMAs (cdna_hip_programming.md 5, "Pipelining across barriers").
 // Rows are 64 B, which makes a ds_read_b128 fragment read 2-way bank conflicted; the 16-B chunk index
 // is XORed with ((row>>3)&1)<<1 on the DMA's SOURCE address and on the fragment read (rule 21).
 // Epilogue: accumulators -> fp32 tile in LDS (XOR-swizzled 16-B chunks) -> each thread owns 8
 // consecutive channels of one pixel: residual planes are read and output planes written as whole
 // 128-B lines (16 B per lane, 16 or 8 lanes per pixel row).
 //
-// Variants (ConvCfg): 128x256 / 64x256 with 8 waves and a 3-stage ring (one workgroup per CU; fewest bytes
-// per FLOP) and 128x128 / 64x128 with 4 waves and a 2-stage ring (two or three workgroups per CU: the
-// HBM-bound epilogue of one overlaps the MFMA-bound K loop of the other, and small layers get more tiles).
+// Variants (ConvCfg): 128x256 with 8 waves and 3-deep rings (one workgroup per CU; fewest bytes per FLOP) and
+// 128x128 with 4 waves, a 2-deep W ring (L2 hits) and a 3-deep X ring (HBM / Infinity Cache latency), 80 KB:
+// two workgroups per CU, so the HBM-bound epilogue of one overlaps the MFMA-bound K loop of the other.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,23 +64,30 @@ struct ConvParams {
     int relu;
 };
 
-template <int TC_, int TP_, int NWR_, int NWC_, int NS_>
+template <int TC_, int TP_, int NWR_, int NWC_, int NSW_, int NSX_>
 struct ConvCfg {
-    static constexpr int TC = TC_, TP = TP_, NWR = NWR_, NWC = NWC_, NS = NS_;
+    static constexpr int TC = TC_, TP = TP_, NWR = NWR_, NWC = NWC_, NSW = NSW_, NSX = NSX_;   // ring depths of W and X
     static constexpr int NW = NWR * NWC, NT = 64 * NW;
     static constexpr int CF = TC / NWR / 16;        // 16-row cout fragments per wave
     static constexpr int PF = TP / NWC / 16;        // 16-col pixel fragments per wave
-    static constexpr int STAGE = (TC + TP) * 128;
+    static constexpr int WSTAGE = TC * 128, XSTAGE = TP * 128;      // [hi rows x 64 B][lo rows x 64 B]
+    static constexpr int XBASE = NSW * WSTAGE;
     static constexpr int WP = TC / 16, XP = TP / 16;            // 1-KiB pieces per plane
     static constexpr bool HALF_W = (2 * WP == NW);              // waves [0,NW/2) move W_hi, the rest W_lo
     static constexpr int WJ = HALF_W ? 1 : WP / NW;             // W pieces per wave per plane
     static constexpr int XJ = XP / NW;                          // X pieces per wave per plane
-    static constexpr int LPT = (HALF_W ? 1 : 2 * WJ) + 2 * XJ;  // DMA instructions per wave per stage
+    static constexpr int LW = HALF_W ? 1 : 2 * WJ, LX = 2 * XJ; // DMA instructions per wave per W / X stage
+    static constexpr int RING = NSW * WSTAGE + NSX * XSTAGE;
     static constexpr int EPI = TP * TC * 4;
-    static constexpr int LDS = NS * STAGE > EPI ? NS * STAGE : EPI;
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    // Per step a wave issues W(ks+NSW) and then X(ks+NSX).  At the top of step ks+1 stage ks+2 must have landed
+    // (its fragments are read during that step): everything issued after W(ks+2) / X(ks+2) may stay in flight.
+    static constexpr int WAIT_W = LX + (NSW - 2) * (LW + LX), WAIT_X = (NSX - 2) * (LW + LX);
+    static constexpr int WAIT_STEP = WAIT_W < WAIT_X ? WAIT_W : WAIT_X;
+    static constexpr int WAIT_PROLOGUE = (NSW - 1) * LW + (NSX - 1) * LX;
     static_assert(HALF_W || WP % NW == 0, "W pieces must divide over the waves");
     static_assert(XP % NW == 0, "X pieces must divide over the waves");
-    static_assert((TC / NWR) % 16 == 0 && (TP / NWC) % 16 == 0 && NS >= 2, "tile shape");
+    static_assert((TC / NWR) % 16 == 0 && (TP / NWC) % 16 == 0 && NSW >= 2 && NSX >= NSW, "tile shape");
 };
 
 template <int N>
@@ -94,9 +101,9 @@ template <class C>
 __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TC = C::TC, TP = C::TP, NS = C::NS, NW = C::NW, NT = C::NT;
-    constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, XJ = C::XJ, LPT = C::LPT, STAGE = C::STAGE;
-    constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = TC * 128, OFF_XLO = TC * 128 + TP * 64;
+    constexpr int TC = C::TC, TP = C::TP, NSW = C::NSW, NSX = C::NSX, NW = C::NW, NT = C::NT;
+    constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, XJ = C::XJ, WSTAGE = C::WSTAGE, XSTAGE = C::XSTAGE, XBASE = C::XBASE;
+    constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = 0, OFF_XLO = TP * 64;     // within a W stage / an X stage
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     // `live` = false (a step past the end of K) keeps the ring and the vmcnt bookkeeping in shape: the X pieces
     // read out of range (zeros), the W pieces read whatever follows the row (never used).
     auto stage_w = [&](int buf, int ks) {
-        char* sb = smem + buf * STAGE;
+        char* sb = smem + buf * WSTAGE;
         const int soff = ks * 64;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
         }
     };
     auto stage_x = [&](int i, int buf, int ky, int kx, int c0, bool live) {
-        char* sb = smem + buf * STAGE;
+        char* sb = smem + XBASE + buf * XSTAGE;
         const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
         const int delta = ((ky * p.win + kx) * p.pix_stride + c0) * 2;      // wave-uniform
         // Out-of-range taps (and steps past the end of K) set the offset's sign bit, which is >= num_records, so
@@ -189,12 +196,6 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb + OFF_XHI + d), 16, voff, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sb + OFF_XLO + d), 16, voff, 0, 0, 0);
     };
-    auto stage = [&](int buf, int ks, int ky, int kx, int c0, bool live) {
-        stage_w(buf, ks);
-#pragma unroll
-        for (int i = 0; i < XJ; ++i) stage_x(i, buf, ky, kx, c0, live);
-    };
-
     f4 acc[CF][PF];
 #pragma unroll
     for (int a = 0; a < CF; ++a)
@@ -221,27 +222,19 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     struct Frags {
         h8 a_hi[CF], a_lo[CF], b_hi[PF], b_lo[PF];
     };
-    auto load_frags = [&](int slot, Frags& f) {
-        const char* sb = smem + slot * STAGE;
-#pragma unroll
-        for (int a = 0; a < CF; ++a) {
-            f.a_hi[a] = *(const h8*)(sb + OFF_WHI + a_off + a * 1024);
-            f.a_lo[a] = *(const h8*)(sb + OFF_WLO + a_off + a * 1024);
-        }
-#pragma unroll
-        for (int b = 0; b < PF; ++b) {
-            f.b_hi[b] = *(const h8*)(sb + OFF_XHI + b_off + b * 1024);
-            f.b_lo[b] = *(const h8*)(sb + OFF_XLO + b_off + b * 1024);
-        }
-    };
     constexpr int NF = 2 * (CF + PF);                   // fragment reads per step
     constexpr int NM = 3 * CF * PF;                     // MFMAs per step
-    auto load_frag = [&](int slot, Frags& f, int j) {   // fragment j of step: a_hi[..] a_lo[..] b_hi[..] b_lo[..]
-        const char* sb = smem + slot * STAGE;
-        if (j < CF) f.a_hi[j] = *(const h8*)(sb + OFF_WHI + a_off + j * 1024);
-        else if (j < 2 * CF) f.a_lo[j - CF] = *(const h8*)(sb + OFF_WLO + a_off + (j - CF) * 1024);
-        else if (j < 2 * CF + PF) f.b_hi[j - 2 * CF] = *(const h8*)(sb + OFF_XHI + b_off + (j - 2 * CF) * 1024);
-        else f.b_lo[j - 2 * CF - PF] = *(const h8*)(sb + OFF_XLO + b_off + (j - 2 * CF - PF) * 1024);
+    auto load_frag = [&](int wslot, int xslot, Frags& f, int j) {   // fragment j: a_hi[..] a_lo[..] b_hi[..] b_lo[..]
+        const char* sw = smem + wslot * WSTAGE;
+        const char* sx = smem + XBASE + xslot * XSTAGE;
+        if (j < CF) f.a_hi[j] = *(const h8*)(sw + OFF_WHI + a_off + j * 1024);
+        else if (j < 2 * CF) f.a_lo[j - CF] = *(const h8*)(sw + OFF_WLO + a_off + (j - CF) * 1024);
+        else if (j < 2 * CF + PF) f.b_hi[j - 2 * CF] = *(const h8*)(sx + OFF_XHI + b_off + (j - 2 * CF) * 1024);
+        else f.b_lo[j - 2 * CF - PF] = *(const h8*)(sx + OFF_XLO + b_off + (j - 2 * CF - PF) * 1024);
+    };
+    auto load_frags = [&](int wslot, int xslot, Frags& f) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) load_frag(wslot, xslot, f, j);
     };
     auto mfma_one = [&](const Frags& f, int i) {        // flat order (a, term, b): neighbours hit different accumulators
         const int a = i / (3 * PF), r = i % (3 * PF), term = r / PF, b = r % PF;
@@ -262,56 +255,61 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
         for (int a = 0; a < CF; ++a) mfma_row(f, a);
     };
 
-    // Pipeline: the fragment registers are one more stage.  While the MFMAs of step ks run from registers,
-    // the fragments of step ks+1 are read from the ring and the DMAs of steps ks+2 .. ks+NS are in flight.
-    // prologue: stages 0..NS-1 issued (dummies past the end of K), fragments of step 0 in registers
+    // Pipeline: the fragment registers are one more stage.  While the MFMAs of step ks run from registers, the
+    // fragments of step ks+1 are read from the rings and the DMAs W(ks+2 .. ks+NSW), X(ks+2 .. ks+NSX) are in
+    // flight.  W and X have rings of their own: X usually comes from HBM / Infinity Cache and gets the deeper one.
+    // prologue: W(0..NSW-1), X(0..NSX-1) issued stage by stage, W before X (dummies past the end of K)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        stage(s, s, ky, kx, c0, s < nk);
+    for (int s = 0; s < NSX; ++s) {
+        if (s < NSW) stage_w(s, s);
+#pragma unroll
+        for (int i = 0; i < XJ; ++i) stage_x(i, s, ky, kx, c0, s < nk);
         advance();
     }
-    wait_vmcnt<(NS - 1) * LPT>();
+    wait_vmcnt<C::WAIT_PROLOGUE>();
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;
-    load_frags(0, fa);
+    load_frags(0, 0, fa);
 
-    int slot = 0;                   // ring slot of step ks
+    int wslot = 0, xslot = 0;       // ring slots of step ks
     // A step that has a successor: frags of ks are in `cur`; leaves frags of ks+1 in `nxt`.  Branch-free, and
     // hand-scheduled: every instruction sits between sched_barrier(0) fences, because the waves of a workgroup
     // leave the barrier in lockstep and an in-order wave that meets a burst (16 fragment reads from 8 waves at
     // once, or a clump of DMA address arithmetic) cannot issue MFMAs behind it.  The order per step is
     //   MFMA 0 (hipcc guards its operands with an lgkmcnt(0) that finds nothing outstanding here),
     //   then one fragment read of step ks+1 after every second MFMA,
-    //   then the 1+XJ DMA groups of step ks+NS spread evenly over the remaining MFMAs.
+    //   then the DMA groups W(ks+NSW), X(ks+NSX) piece by piece, spread evenly over the remaining MFMAs.
     auto full_step = [&](int ks, const Frags& cur, Frags& nxt) {
-        // own pieces of stage ks+1 landed (younger stages stay in flight), and -- lgkmcnt(0) -- this wave's
-        // reads of slot(ks) returned; the barrier then frees slot(ks) for stage ks+NS
+        // own pieces of stage ks+1 landed (younger ones stay in flight), and -- lgkmcnt(0) -- this wave's reads of
+        // the slots of step ks returned; the barrier then frees them for W(ks+NSW) and X(ks+NSX)
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(NS - 2) * LPT>();
+        wait_vmcnt<C::WAIT_STEP>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
-        const bool live = ks + NS < nk;
+        const int nw = (wslot + 1 == NSW) ? 0 : wslot + 1;
+        const int nx = (xslot + 1 == NSX) ? 0 : xslot + 1;
+        const bool live = ks + NSX < nk;
         constexpr int G = 1 + XJ;                       // DMA groups: W, X piece 0, X piece 1, ...
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             mfma_one(cur, i);
             __builtin_amdgcn_sched_barrier(0);
             if ((i & 1) == 0 && i / 2 < NF) {
-                load_frag(nslot, nxt, i / 2);
+                load_frag(nw, nx, nxt, i / 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (i == (((2 * g + 1) * NM) / (2 * G) | 1)) {
-                    if (g == 0) stage_w(slot, ks + NS);
-                    else stage_x(g - 1, slot, ky, kx, c0, live);
+                    if (g == 0) stage_w(wslot, ks + NSW);
+                    else stage_x(g - 1, xslot, ky, kx, c0, live);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         advance();
-        slot = nslot;
+        wslot = nw;
+        xslot = nx;
     };
     int ks = 0;
     for (; ks + 2 < nk; ks += 2) {
@@ -401,10 +399,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
 }
 
 // Tile variants selectable per layer (mpx_set_conv_tile).
-typedef ConvCfg<128, 256, 2, 4, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
-typedef ConvCfg<64, 256, 1, 4, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
-typedef ConvCfg<128, 128, 2, 2, 2> ConvTile2;   // 4 waves, 64 KB LDS, 2 workgroups / CU
-typedef ConvCfg<128, 64, 2, 2, 2> ConvTile3;    // narrow pixel tile: 48 KB LDS, 3 workgroups / CU (measured slower than tile 2 everywhere)
+typedef ConvCfg<128, 256, 2, 4, 3, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
+typedef ConvCfg<64, 256, 1, 4, 2, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
+typedef ConvCfg<128, 128, 2, 2, 2, 2> ConvTile2;   // 4 waves, 2-deep rings, 64 KB LDS, 2 workgroups / CU
+typedef ConvCfg<128, 128, 2, 2, 2, 3> ConvTile3;   // as tile 2 with a 3-deep X ring (80 KB): measured 5-11 % slower (2 x 80 KB no longer co-reside)
 constexpr int CONV_NUM_TILES = 4;
 
 }  // namespace mpx
