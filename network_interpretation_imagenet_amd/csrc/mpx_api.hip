@@ -67,7 +67,6 @@ struct mpx_engine {
     half_t* pool_hi = nullptr;
     half_t* pool_lo = nullptr;
     float* logits = nullptr;
-    half_t* zero_page = nullptr;
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
     bool prof_on = false;
@@ -259,7 +258,6 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     std::memset(&p, 0, sizeof p);
     p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.scale = L.scale; p.shift = L.shift;
     p.r_hi = r_hi; p.r_lo = r_lo; p.y_hi = y_hi; p.y_lo = y_lo; p.y_f32 = y_f32;
-    p.zero_page = h->zero_page;
     p.cout = L.d.cout;
     p.relu = L.d.relu;
     p.ktot = L.d.k_packed;
@@ -358,7 +356,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return (int)e; }
 
-    // one arena: zero page | input planes | activation planes | pooled | logits | weights
+    // one arena: scratch | input planes | activation planes | pooled | logits | weights
     const size_t in_plane = round_up((size_t)max_batch * MPX_IMG_PAD * MPX_IMG_PAD * 4 * 2 + 256, 256);
     const size_t act_plane = round_up((size_t)max_batch * kActElemsPerImage * 2, 256);
     const size_t pool_plane = round_up((size_t)max_batch * h->feat * 2, 256);
@@ -367,13 +365,12 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     for (const ConvLayer& L : h->convs)
         wbytes += 2 * round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
     const size_t scratch_bytes = 4096 * sizeof(float);
-    const size_t total = 256 + scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
+    const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
     h->arena_bytes = total;
     char* cur = h->arena;
     auto take = [&](size_t n) { char* r = cur; cur += n; return r; };
-    h->zero_page = (half_t*)take(256);
     h->seg_scratch = (float*)take(scratch_bytes);
     h->in_hi = (half_t*)take(in_plane);
     h->in_lo = (half_t*)take(in_plane);
@@ -392,8 +389,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         L.scale = (float*)take(sb);
         L.shift = (float*)take(sb);
     }
-    // zero page and the never-written borders of the input staging must be zero
-    e = hipMemset(h->arena, 0, 256 + scratch_bytes + 2 * in_plane);
+    // the never-written borders of the input staging must be zero
+    e = hipMemset(h->arena, 0, scratch_bytes + 2 * in_plane);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);

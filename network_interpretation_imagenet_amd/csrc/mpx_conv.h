@@ -51,7 +51,6 @@ struct ConvParams {
     half_t* y_hi;            // output planes [M][cout]
     half_t* y_lo;
     float* y_f32;            // fp32 output [M][cout] (fc) or null
-    const half_t* zero_page; // >= 64 zero bytes, 16-B aligned
     int hin, win;            // input spatial extent the bounds check uses
     int pix_stride;          // fp16 elements between adjacent input pixels
     int ho, wo;
@@ -85,6 +84,7 @@ struct ConvCfg {
     static constexpr int WAIT_W = LX + (NSW - 2) * (LW + LX), WAIT_X = (NSX - 2) * (LW + LX);
     static constexpr int WAIT_STEP = WAIT_W < WAIT_X ? WAIT_W : WAIT_X;
     static constexpr int WAIT_PROLOGUE = (NSW - 1) * LW + (NSX - 1) * LX;
+    static constexpr int DMA_FIRST = 1;                         // MFMA index after which the first DMA group is issued
     static_assert(HALF_W || WP % NW == 0, "W pieces must divide over the waves");
     static_assert(XP % NW == 0, "X pieces must divide over the waves");
     static_assert((TC / NWR) % 16 == 0 && (TP / NWC) % 16 == 0 && NSW >= 2 && NSX >= NSW, "tile shape");
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     // once, or a clump of DMA address arithmetic) cannot issue MFMAs behind it.  The order per step is
     //   MFMA 0 (hipcc guards its operands with an lgkmcnt(0) that finds nothing outstanding here),
     //   then one fragment read of step ks+1 after every second MFMA,
-    //   then the DMA groups W(ks+NSW), X(ks+NSX) piece by piece, spread evenly over the remaining MFMAs.
+    //   with the DMA groups W(ks+NSW), X(ks+NSX) piece by piece after MFMAs 1, 5, 9, ... (early, so that they have
+    //   the rest of the step to land).
     auto full_step = [&](int ks, const Frags& cur, Frags& nxt) {
         // own pieces of stage ks+1 landed (younger ones stay in flight), and -- lgkmcnt(0) -- this wave's reads of
         // the slots of step ks returned; the barrier then frees them for W(ks+NSW) and X(ks+NSX)
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (i == (((2 * g + 1) * NM) / (2 * G) | 1)) {
+                if (i == C::DMA_FIRST + 4 * g) {      // early in the step: the pieces need the rest of it to land
                     if (g == 0) stage_w(wslot, ks + NSW);
                     else stage_x(g - 1, xslot, ky, kx, c0, live);
                     __builtin_amdgcn_sched_barrier(0);
