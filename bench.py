@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent forward batches in flight (one engine + HIP stream each): lets the HBM-bound "
                          "kernels of one batch overlap the MFMA-bound kernels of another")
+    ap.add_argument("--stream-offset", action="store_true", help="with --streams > 1: start the streams out of phase")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
     return ap.parse_args()
@@ -133,6 +134,13 @@ def main():
     def step(profile):
         for st in streams:
             st.wait_stream(torch.cuda.current_stream(dev))
+        if len(engines) > 1 and args.stream_offset:
+            # put stream k a fraction k/n of a forward behind stream 0, so that one stream's HBM-bound layers
+            # meet another's MFMA-bound layers instead of running the same layer side by side
+            for k in range(1, len(engines)):
+                with torch.cuda.stream(streams[k]):
+                    nb = batch * k // len(engines)
+                    engines[k].forward(nb, label_rows[:ipf].view(-1)[:nb].contiguous())
         for f, i0 in enumerate(range(0, n_img, ipf)):
             e, st = engines[f % len(engines)], streams[f % len(engines)]
             prof = profile and (f % PROFILE_EVERY == 0) and e is eng

@@ -67,3 +67,24 @@ def score_sharded(score_image_fn, num_images, masks_per_image, device, group=Non
     pieces = [score_image_fn(img, m_lo, m_hi) for img, m_lo, m_hi in image_ranges(lo, hi, masks_per_image)]
     local = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.float32, device=device)
     return all_gather_blocks(local, total, group)
+
+
+def score_masks_sharded(engine, image, segments, onoff, label, group=None):
+    """Single-image case (BASELINE config 5: one image, every candidate window of a BO round): shard the MASK
+    axis, every rank holds the image.  Each rank scores its contiguous block of mask-vectors with its own engine
+    and one all-gather returns the full (score f32[M], pred i32[M]) on every rank -- bit-identical to one engine
+    scoring all M (same kernels, disjoint blocks)."""
+    import numpy as np
+    m = int(onoff.shape[0])
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = block(m, rank, world)
+    _o, score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+    device = getattr(engine, "device", torch.device("cpu"))
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
+    s_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(score)).to(device), m, group)
+    p_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(pred)).to(device), m, group)
+    return s_all.cpu().numpy(), p_all.cpu().numpy()

@@ -58,3 +58,40 @@ def test_two_rank_gather_matches_single_process(tmp_path, n_img, n_mask):
         calls = np.load(tmp_path / ("calls%d.npy" % r))
         covered += int((calls[:, 2] - calls[:, 1]).sum())
     assert covered == n_img * n_mask                                  # disjoint blocks, nothing scored twice
+
+
+class _TableEngine:
+    """Engine stand-in whose score is a pure function of the mask-vector (no GPU, no oracle)."""
+    device = torch.device("cpu")
+
+    def score_masks(self, image, segments, onoff, label):
+        w = np.arange(1, onoff.shape[1] + 1, dtype=np.float64)
+        v = (onoff.astype(np.float64) * w).sum(1)
+        return onoff, (np.sin(v) * 0.5 + 0.5).astype(np.float32), (v.astype(np.int64) % 7).astype(np.int32)
+
+
+def _mask_worker(rank, world, port, m, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
+        score, pred = shard.score_masks_sharded(_TableEngine(), None, None, onoff, 0)
+        np.savez(os.path.join(out_dir, "m%d.npz" % rank), score=score, pred=pred)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m", [24, 7, 1])
+def test_mask_axis_sharding_single_image(tmp_path, m):
+    """Config-5 shape: one image, the mask axis split over two ranks, one all-gather."""
+    mp.spawn(_mask_worker, args=(2, _free_port(), m, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(5)
+    onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
+    _o, want_s, want_p = _TableEngine().score_masks(None, None, onoff, 0)
+    single = shard.score_masks_sharded(_TableEngine(), None, None, onoff, 0)
+    assert (single[0] == want_s).all() and (single[1] == want_p).all()
+    for r in range(2):
+        got = np.load(tmp_path / ("m%d.npz" % r))
+        assert (got["score"] == want_s).all() and (got["pred"] == want_p).all()
