@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import masks
-from .engine import BasePredictionWrong, MaskedForwardEngine, rank_segments, IMG
+from .engine import BasePredictionWrong, rank_segments, IMG
 
 __all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
            "validate", "validate_summed", "score_masks", "default_segmenter", "img_show_u8",

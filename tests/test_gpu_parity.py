@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from network_interpretation_imagenet_amd import _lib, masks, synth
 from network_interpretation_imagenet_amd.engine import MaskedForwardEngine, MpxError
-from oracle import resnet_ref, scorer
+from oracle import scorer
 
 pytestmark = pytest.mark.gpu
 

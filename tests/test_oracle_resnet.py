@@ -1,6 +1,5 @@
 """Known answers that pin the CPU oracle's ResNet restatement.  The reference
 ships no tests or fixtures for this path (parity unpinned), so these are the anchors."""
-import numpy as np
 import pytest
 import torch
 

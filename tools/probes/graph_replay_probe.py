@@ -1,8 +1,8 @@
 import os, sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g; g.build()
-from network_interpretation_imagenet_amd import masks, synth
+from network_interpretation_imagenet_amd import synth
 from network_interpretation_imagenet_amd.engine import MaskedForwardEngine
 eng = MaskedForwardEngine("resnet101", max_batch=128, device=0).load_state_dict(synth.make_state_dict("resnet101"))
 dev = eng.device
