@@ -127,6 +127,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     // images); W descriptors start at the tile's first cout row and the K step is the SGPR soffset.  Per step a
     // lane spends ~5 VALU per X piece (tap bounds test, one add, one select to the out-of-range offset that
     // makes the buffer unit return zeros) and none per W piece.
+    const int nk = p.ktot >> 5;
     const int prow = lane >> 2;                                      // row within a 16-row piece
     const int src_q = ((lane & 3) ^ (((prow >> 3) & 1) << 1)) * 8;   // swizzled source chunk, in elements
     const int howo = p.ho * p.wo;
@@ -169,17 +170,20 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
     auto stage_w = [&](int buf, int ks) {
         char* sb = smem + buf * WSTAGE;
         const int soff = ks * 64;
+        // a step past the end of K only keeps the vmcnt bookkeeping in shape: an out-of-range offset makes the
+        // buffer unit return zeros without a memory access, so the drain in front of the epilogue is short
+        const int dead = ks < nk ? 0 : (int)OOB;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             if (C::HALF_W) {
                 if (wave < NW / 2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j], soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j], soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
             } else {
                 const int d = (j * NW + wave) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j], soff, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j] | dead, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j] | dead, soff, 0, 0);
             }
         }
     };
@@ -202,7 +206,6 @@ __global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p
 #pragma unroll
         for (int b = 0; b < PF; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.ktot >> 5;
     int ky = 0, kx = 0, c0 = 0;     // coordinates of the NEXT step to stage
     auto advance = [&]() {      // branch-free (the K step must stay one basic block for the scheduler)
         c0 += 32;
