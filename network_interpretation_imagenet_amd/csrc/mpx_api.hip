@@ -232,7 +232,8 @@ struct ProfScope {
 
 template <class Cfg>
 int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
-    p.n_tiles_c = cout_pad / Cfg::TC;
+    p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;     // weights are padded to cout_pad >= n_tiles_c * TC rows
+    if (p.n_tiles_c * Cfg::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
     const int n_tiles_p = (p.M + Cfg::TP - 1) / Cfg::TP;
     const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
@@ -241,13 +242,14 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     return 0;
 }
 
-// Default variant per layer, from tools/tile_sweep.sh on MI355X at batch 2048 (profiles/r01_tile_sweep_b2048.txt):
-// the 128x128 tile with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound
-// epilogue overlaps the other's K loop) and on cout = 64 layers even though half of its MFMA rows multiply zero
-// padding (a K step has a fixed cost that the 64-row tiles do not amortise); wide 3x3 layers are within noise
-// on both big tiles and keep the 128x256 tile (fewest L2 bytes per FLOP).  Tiles 1, 3 stay selectable.
+// Default variant per layer, from tools/tile_sweep.sh and in-network tools/layer_profile.py runs on MI355X at
+// batch 2048: cout <= 64 layers take a 64-row tile (no zero-padded MFMA rows); of the rest, the 128x128 tile
+// with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound epilogue overlaps the
+// other's K loop) and wide 3x3 layers keep the 128x256 tile (fewest L2 bytes per FLOP; 7 % faster in the
+// network although the isolated layer bench prefers 128x128).  Every tile stays selectable.
 int default_tile(const mpx_conv_desc& d) {
-    return (d.ksize == 3 && d.cout >= 128) ? 0 : 2;
+    if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;
+    return d.ksize == 3 ? 0 : 2;
 }
 
 int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
@@ -281,7 +283,9 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
-        default: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+        case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+        case 4: return launch_conv_tile<ConvTile4>(h, p, L.d.cout_pad, st);
+        default: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
     }
 }
 
@@ -400,6 +404,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
     *out = h;
     return 0;

@@ -63,9 +63,10 @@ struct ConvParams {
     int relu;
 };
 
-template <int TC_, int TP_, int NWR_, int NWC_, int NSW_, int NSX_>
+template <int TC_, int TP_, int NWR_, int NWC_, int NSW_, int NSX_, int MINB_ = 2>
 struct ConvCfg {
     static constexpr int TC = TC_, TP = TP_, NWR = NWR_, NWC = NWC_, NSW = NSW_, NSX = NSX_;   // ring depths of W and X
+    static constexpr int MINB = MINB_;              // workgroups per CU the register budget is sized for
     static constexpr int NW = NWR * NWC, NT = 64 * NW;
     static constexpr int CF = TC / NWR / 16;        // 16-row cout fragments per wave
     static constexpr int PF = TP / NWC / 16;        // 16-col pixel fragments per wave
@@ -98,7 +99,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT, 2) void conv_f16x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TC = C::TC, TP = C::TP, NSW = C::NSW, NSX = C::NSX, NW = C::NW, NT = C::NT;
@@ -407,6 +408,8 @@ typedef ConvCfg<128, 256, 2, 4, 3, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 wor
 typedef ConvCfg<64, 256, 1, 4, 2, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
 typedef ConvCfg<128, 128, 2, 2, 2, 2> ConvTile2;   // 4 waves, 2-deep rings, 64 KB LDS, 2 workgroups / CU
 typedef ConvCfg<128, 128, 2, 2, 2, 3> ConvTile3;   // as tile 2 with a 3-deep X ring (80 KB): measured 5-11 % slower (2 x 80 KB no longer co-reside)
-constexpr int CONV_NUM_TILES = 4;
+typedef ConvCfg<64, 192, 1, 4, 2, 2> ConvTile4;    // cout <= 64: 64 KB LDS, 2 workgroups / CU
+typedef ConvCfg<64, 128, 2, 2, 2, 2, 3> ConvTile5; // cout <= 64: 48 KB LDS, 3 workgroups / CU
+constexpr int CONV_NUM_TILES = 6;
 
 }  // namespace mpx

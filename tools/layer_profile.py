@@ -22,6 +22,13 @@ img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
 seg = torch.from_numpy(synth.grid_segments()).to(dev)
 onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
 labels = torch.zeros(batch, dtype=torch.int32, device=dev)
+if os.environ.get("MPX_TILE_C64"):      # tool-only override: one tile variant on every cout <= 64 conv
+    for i, d in enumerate(eng.layers):
+        if d.cout <= 64:
+            eng.set_conv_tile(i, int(os.environ["MPX_TILE_C64"]))
+if os.environ.get("MPX_TILE_ALL"):      # tool-only override: force one tile variant on every conv
+    for i in range(len(eng.layers)):
+        eng.set_conv_tile(i, int(os.environ["MPX_TILE_ALL"]))
 for _ in range(2):
     eng.stage_masks(img, seg, onoff, 0)
     eng.forward(batch, labels)
