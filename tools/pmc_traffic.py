@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HBM bytes of the conv launches per forward batch from two rocprofv3 --pmc passes over
+`tools/layer_profile.py <arch> <batch> <reps>` (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+usage: python tools/pmc_traffic.py <fetch-pass-dir> <write-pass-dir> <arch> <batch> <forward-batches-profiled> > profiles/rNN_pmc_traffic.json
+Units and corrections as MI355X_MICROARCH.md (HBM) prescribes: the counters are KiB; WRITE_SIZE is exact for
+16-B-per-lane streaming stores; FETCH_SIZE tallies 128-B requests at 64 B and is doubled."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def total(path, counter, sub="conv_f16x3"):
+    s, n = 0.0, 0
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if sub in row.get("Kernel_Name", "") and row["Counter_Name"] == counter:
+                    s += float(row["Counter_Value"])
+                    n += 1
+    return s, n
+
+
+fetch_dir, write_dir, arch, batch, nb = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+f, nf = total(fetch_dir, "FETCH_SIZE")
+w, nw = total(write_dir, "WRITE_SIZE")
+assert nf and nf == nw and nf % nb == 0, (nf, nw, nb)
+launches = nf // nb
+fetch = f * 1024 / nb
+write = w * 1024 / nb
+print(json.dumps({
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) --kernel-trace -- python3 tools/layer_profile.py "
+              "%s %d; conv_f16x3_kernel launches only, per forward batch of %d masked images" % (arch, batch, batch),
+    "arch": arch,
+    "forward_batch": batch,
+    "launches_per_batch": launches,
+    "write_bytes_per_batch": write,
+    "fetch_raw_bytes_per_batch": fetch,
+    "fetch_corrected_bytes_per_batch_guide_x2": 2 * fetch,
+    "traffic_bytes_per_launch": (2 * fetch + write) / launches,
+}, indent=1))
