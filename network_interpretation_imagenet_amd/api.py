@@ -22,7 +22,9 @@ from . import masks
 from .engine import BasePredictionWrong, rank_segments, IMG
 
 __all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
-           "validate", "validate_summed", "score_masks", "default_segmenter", "img_show_u8",
+           "validate", "validate_summed", "validate_summed_many", "score_masks", "default_segmenter",
+           "img_show_u8", "load_images_from_folder", "prepare_training_data", "get_pixel_sorted_mask_label",
+           "summed_heatmap_from_folder",
            "BasePredictionWrong", "configure"]
 
 _CONFIG = {"eval_img_index": 1, "num_mask_samples": 100, "segmenter": None, "mask_dir": None, "seed": None}
@@ -44,15 +46,11 @@ def configure(**kw):
 
 def default_segmenter(img_u8_hwc):
     """felzenszwalb(img_as_float(img_show), scale=100, sigma=0.5, min_size=50)
-    (generate_gp_training_data_imagenet.py:183).  skimage is a third-party CPU dependency of the
-    reference that this image does not ship; pass `segmenter=` to configure() when it is absent."""
-    try:
-        from skimage.segmentation import felzenszwalb
-        from skimage.util import img_as_float
-    except ImportError as e:   # pragma: no cover - depends on the environment
-        raise ImportError("skimage is not installed; configure(segmenter=callable) with a function "
-                          "u8[224,224,3] -> int[224,224]") from e
-    return felzenszwalb(img_as_float(img_u8_hwc), scale=100, sigma=0.5, min_size=50)
+    (generate_gp_training_data_imagenet.py:183) by the native CPU front-end (segment.py / libmpxseg.so,
+    bit-exact against scikit-image 0.18.3 on the committed vectors); configure(segmenter=callable)
+    swaps in anything else that maps u8[224,224,3] -> int[224,224]."""
+    from . import segment
+    return segment.felzenszwalb(img_u8_hwc, scale=100, sigma=0.5, min_size=50)
 
 
 def img_show_u8(input_chw):
@@ -235,6 +233,114 @@ def validate_summed(val_loader, model, criterion, eval_img_index, num_mask_sampl
     onoff = masks.windows_onoff(s.num_segments, firsts)
     per_segment = (onoff * correct[:, None].astype(np.uint8)).sum(0).astype(np.float64)
     return per_segment[s.seg_rank]
+
+
+def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mask_samples=None, rng=None,
+                         workers=4, lookahead=None):
+    """validate_summed for several images of one pass over the loader: {index: f64[224,224] or None}
+    (None where the unmasked prediction is wrong, the reference's "wrong prediction" branch).
+    The CPU segmentation of the next images (segment.SegmenterPool) runs while the GPU scores the
+    current one -- the reference segments and scores strictly one after the other
+    (gp_superpixel_data_imagenet.py:206-232)."""
+    from collections import deque
+    from . import segment
+    n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
+    want = set(int(i) for i in eval_img_indices)
+    if not want:
+        return {}
+    custom = _CONFIG["segmenter"]
+    lookahead = int(lookahead or 2 * workers)
+    rng = rng or (random.Random(_CONFIG["seed"]) if _CONFIG["seed"] is not None else random)
+    out = {}
+    pending = deque()
+
+    def finish(idx, x, target, fut):
+        try:
+            s = SaliencySession(model, x, target, segments=fut.result())
+        except BasePredictionWrong:
+            out[idx] = None
+            return
+        firsts = masks.draw_first_indices(s.num_segments, n, rng)
+        _score, table_pred = s.table()
+        correct = np.array([table_pred[f] for f in firsts], dtype=np.int64) == s.label
+        onoff = masks.windows_onoff(s.num_segments, firsts)
+        per_segment = (onoff * correct[:, None].astype(np.uint8)).sum(0).astype(np.float64)
+        out[idx] = per_segment[s.seg_rank]
+
+    with segment.SegmenterPool(workers=workers) as pool:
+        count = 0
+        for item in val_loader:
+            count += 1
+            if count in want:
+                x = torch.as_tensor(item[0])
+                x = (x[0] if x.dim() == 4 else x).contiguous()
+                if custom is not None:
+                    fut = pool._ex.submit(lambda a=x.numpy().copy(): custom(img_show_u8(a)))
+                else:
+                    fut = pool.submit(x.numpy())
+                pending.append((count, x, item[1], fut))
+                if len(pending) > lookahead:
+                    finish(*pending.popleft())
+            if count >= max(want):
+                break
+        while pending:
+            finish(*pending.popleft())
+    return out
+
+
+def load_images_from_folder(folder):
+    """-> (img_filenames, labels): every file of `folder`, label = the text between the second '_' and the
+    first '.' of `mask_{i}_{label}.png` (gp_regression.py:63-72; generate_gp_training_data_imagenet.py:474-483).
+    Listing order is os.listdir's, as upstream."""
+    img_filenames, labels = [], []
+    for filename in os.listdir(folder):
+        labels.append(filename.split('_')[2].split('.')[0])
+        img_filenames.append(os.path.join(folder, filename))
+    return img_filenames, labels
+
+
+def _summed_from_folder(folder, n):
+    from PIL import Image
+    files, labels = load_images_from_folder(folder)
+    summed = np.zeros((n, n), dtype=np.int64)
+    seen = np.zeros((n, n), dtype=bool)
+    correct = 0
+    for path, lab in zip(files, labels):
+        img = np.asarray(Image.open(path).convert("L"))        # cv2.imread(path, 0)
+        if img.shape != (n, n):
+            raise ValueError("%s is %s, expected %dx%d" % (path, img.shape, n, n))
+        on = img == 255
+        lab = int(lab)
+        correct += lab == 1
+        summed += on * lab
+        seen |= on
+    return summed, seen, len(files), correct
+
+
+def get_pixel_sorted_mask_label(folder='./masks', n=IMG):
+    """-> dict {(row, col): sum of the labels of the masks that keep this pixel}, only pixels some mask keeps
+    (generate_gp_training_data_imagenet.py:490-516), read back from the PNG wire format validate() writes."""
+    summed, seen, total, correct = _summed_from_folder(folder, n)
+    print("%d samples, the corrrect prediction number: %d " % (total, correct))
+    rows, cols = np.nonzero(seen)
+    return {(int(r), int(c)): int(summed[r, c]) for r, c in zip(rows, cols)}
+
+
+def summed_heatmap_from_folder(folder='./masks/', n=IMG):
+    """-> result_gray_img f64[n,n] = sum_i label_i * [mask_i == 255] (gp_regression.py:82-101)."""
+    return _summed_from_folder(folder, n)[0].astype(np.float64)
+
+
+def prepare_training_data(folder='./masks/', n=IMG):
+    """-> (train_x f32[P,2], train_y f32[P]) torch tensors: the GP's training set, gp_regression.py:74-153
+    (pixels some mask keeps, raster order; y[p] = sum_i label_i * [mask_i[p] == 255]).  Upstream moves them to
+    the GPU for gpytorch; here they stay on the host (the GP is the caller's).  One vectorised pass per PNG
+    instead of upstream's n*n Python loop per PNG; the JET picture (:107-124) is plotting and not produced."""
+    summed, seen, _total, _correct = _summed_from_folder(folder, n)
+    rows, cols = np.nonzero(seen)
+    train_x = torch.from_numpy(np.stack([rows, cols], axis=1).astype(np.float32))
+    train_y = torch.from_numpy(summed[rows, cols].astype(np.float32))
+    return train_x, train_y
 
 
 def score_masks(model, image, segments, onoff, label):

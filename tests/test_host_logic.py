@@ -234,6 +234,49 @@ def test_api_validate_generators(coarse_setup):
     assert int((pred == label).sum()) == n_ok
 
 
+def test_api_png_wire_format_round_trip(coarse_setup):
+    """validate() writes mask_{i}_{label}.png; the consumer side (gp_regression.py:63-104,
+    generate_gp_training_data_imagenet.py:490-516) reads them back into the same heat map validate_summed builds."""
+    eng, loader, _seg, _label, mask_dir = coarse_setup
+    n_ok = api.validate(loader, eng, None, 2)
+    summed = api.validate_summed(loader, eng, None, 2)               # same seed -> same draws
+    files, labels = api.load_images_from_folder(str(mask_dir))
+    assert len(files) == 12 and sorted(set(labels)) <= ["0", "1"] and labels.count("1") == n_ok
+    assert (api.summed_heatmap_from_folder(str(mask_dir)) == summed).all()
+    d = api.get_pixel_sorted_mask_label(str(mask_dir))
+    train_x, train_y = api.prepare_training_data(str(mask_dir))
+    assert train_x.dtype == torch.float32 and train_x.shape == (len(d), 2) and train_y.shape == (len(d),)
+    xs = train_x.numpy().astype(int)
+    assert (np.diff(xs[:, 0] * 224 + xs[:, 1]) > 0).all()             # raster order, each pixel once
+    assert all(d[(r, c)] == int(y) == int(summed[r, c]) for (r, c), y in zip(xs[::97].tolist(), train_y.numpy()[::97]))
+    assert all(summed[r, c] == 0 for r, c in [(0, 0), (223, 223)] if (r, c) not in d)
+
+
+def test_api_validate_summed_many_pipelines_segmentation(coarse_setup):
+    eng, loader, seg, label, _ = coarse_setup
+    loader3 = loader + [loader[1]]
+    one = api.validate_summed(loader3, eng, None, 2, rng=random.Random(9))
+    many = api.validate_summed_many(loader3, eng, None, [2], rng=random.Random(9), workers=2)
+    assert list(many) == [2] and (many[2] == one).all()
+    r = random.Random(9)
+    both = api.validate_summed_many(loader3, eng, None, [3, 2], rng=r, workers=2, lookahead=1)
+    assert sorted(both) == [2, 3] and (both[2] == one).all() and both[3].shape == (224, 224)
+    bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
+    assert api.validate_summed_many(bad, eng, None, [2], workers=1) == {2: None}
+    assert api.validate_summed_many(loader, eng, None, []) == {}
+
+
+def test_default_segmenter_is_the_native_front_end():
+    from network_interpretation_imagenet_amd import segment
+    x = scorer.to_tensor_normalize(synth.make_images(1)[0])
+    pic = api.img_show_u8(x.numpy())
+    assert (pic == segment.minmax_u8(x.numpy())).all()
+    seg = api.default_segmenter(pic)
+    assert seg.dtype == np.int64 and seg.shape == (224, 224) and (seg == segment.felzenszwalb(pic)).all()
+    s = api.SaliencySession(FakeEngine(), x, 0, check_base=False)      # segmentation only: no forward is run
+    assert s.num_segments == int(seg.max()) + 1 and s.window == int(0.4 * s.num_segments)
+
+
 def test_api_wrong_base_prediction(coarse_setup):
     eng, loader, _seg, label, _ = coarse_setup
     bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
