@@ -429,6 +429,30 @@ def test_heatmap_accumulate_exact(eng18, dev, golden_dir):
     assert eng18._lib.mpx_heatmap_accumulate(eng18._h, None, None, None, None, 1, 1, None, None) == -1
 
 
+def test_pipelined_heat_maps_with_native_segmentation(eng18):
+    """Row f3 + f2 end to end: api.validate_summed_many segments three images on the host pool (libmpxseg.so)
+    while the engine scores; image 2's heat map is checked against the oracle's literal accumulation."""
+    import random
+    from network_interpretation_imagenet_amd import api, segment
+    imgs = synth.make_images(3, seed=77, kind="blobs")
+    xs = [scorer.to_tensor_normalize(im) for im in imgs]
+    labels = [eng18.predict(x)[0] for x in xs]
+    loader = [(x[None], torch.tensor([lab])) for x, lab in zip(xs, labels)]
+    api.configure(segmenter=None, num_mask_samples=10, mask_dir=None, seed=None)
+    try:
+        maps = api.validate_summed_many(loader, eng18, None, [1, 2, 3], rng=random.Random(3), workers=3)
+        assert sorted(maps) == [1, 2, 3] and all(m.shape == (224, 224) for m in maps.values())
+        only2 = api.validate_summed_many(loader, eng18, None, [2], rng=random.Random(4), workers=1)[2]
+        seg = segment.felzenszwalb(api.img_show_u8(xs[1].numpy()))
+        S = int(seg.max()) + 1
+        firsts = masks.draw_first_indices(S, 10, random.Random(4))
+        onoff = masks.windows_onoff(S, firsts)
+        _s, pred = scorer.score_masks_batched(synth.make_state_dict("resnet18"), "resnet18", xs[1], seg, onoff, labels[1], chunk=10)
+        assert (only2 == scorer.summed_superpixel_labels(seg, onoff, pred == labels[1])).all()
+    finally:
+        api.configure(segmenter=None, num_mask_samples=100, mask_dir=None, seed=None)
+
+
 def test_engine_errors(eng18, dev):
     img = synth.make_images(1)[0]
     seg = synth.grid_segments()

@@ -277,6 +277,17 @@ def test_default_segmenter_is_the_native_front_end():
     assert s.num_segments == int(seg.max()) + 1 and s.window == int(0.4 * s.num_segments)
 
 
+def test_native_segmenter_reproduces_committed_skimage_segments():
+    """tests/golden/segments_blobs.npz holds scikit-image's label maps of img_show of the seeded blob images
+    (make_segments.py); the native front-end must give the same maps from the same tensors."""
+    from network_interpretation_imagenet_amd import segment
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "segments_blobs.npz"))
+    imgs = synth.make_images(2, seed=int(gold["image_seed"]), kind="blobs")
+    for im, want in zip(imgs, gold["segments"]):
+        pic = api.img_show_u8(scorer.to_tensor_normalize(im).numpy())
+        assert (segment.felzenszwalb(pic) == want).all()
+
+
 def test_api_wrong_base_prediction(coarse_setup):
     eng, loader, _seg, label, _ = coarse_setup
     bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
