@@ -110,3 +110,19 @@ def random_onoff(m, s, seed=4321, p=0.4):
     """Bernoulli(p) mask-vectors u8[m,s]."""
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(m, s, generator=g) < p).to(torch.uint8).numpy()
+
+
+def transplant_trained_layers(sd, npz_path):
+    """ResNet-18/34 state_dict with layer1's four 64->64 3x3 conv + BN pairs replaced by the TRAINED pairs of
+    tests/golden/trained_layers_cifar_resnet56.npz (the reference's shipped CIFAR ResNet-56, layer3.4 / layer3.8):
+    the only real trained weights available offline that have a shape this engine runs.  Returns a new dict."""
+    g = np.load(npz_path)
+    out = dict(sd)
+    slots = ["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"]
+    for n, conv in enumerate(slots):
+        bn = conv.replace("conv", "bn")
+        assert tuple(out[conv + ".weight"].shape) == (64, 64, 3, 3)
+        out[conv + ".weight"] = torch.from_numpy(g["w%d" % n].copy())
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            out["%s.%s" % (bn, k)] = torch.from_numpy(g["bn%d_%s" % (n, k)].copy())
+    return out

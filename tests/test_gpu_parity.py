@@ -202,6 +202,39 @@ def test_conv_every_tile_variant(eng101, name, tile):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
 
 
+TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_layers_cifar_resnet56.npz")
+
+
+@pytest.fixture(scope="module")
+def eng18_trained(mpx_lib, dev):
+    sd = synth.transplant_trained_layers(synth.make_state_dict("resnet18"), TRAINED)
+    e = MaskedForwardEngine("resnet18", max_batch=64, device=0).load_state_dict(sd)
+    yield e, sd
+    e.close()
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 2, 5])
+@pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"])
+def test_conv_trained_cifar_weights(eng18_trained, name, tile):
+    """Real trained conv + BN pairs (reference checkpoint cifar10+-resnet-56, layer3.4 / layer3.8; BN variances from
+    0.005 to 11) through the conv kernel, against the fp64 conv on the same split inputs."""
+    eng, sd = eng18_trained
+    _check_layer(eng, sd, name, batch=3, tile=tile)
+
+
+def test_trained_layers_end_to_end_scores(eng18_trained):
+    """ResNet-18 with its layer1 replaced by the trained CIFAR pairs: masked scores against the CPU loop."""
+    eng, sd = eng18_trained
+    img = synth.make_images(1, seed=5)[0]
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(12, 196, seed=2)
+    label, _ = eng.predict(img)
+    _o, score, pred = eng.score_masks(img, seg, onoff, label)
+    ref_score, ref_pred = scorer.score_masks_reference_loop(sd, "resnet18", scorer.to_tensor_normalize(img), seg, onoff, label)
+    assert np.abs(score - ref_score).max() <= SCORE_TOL_TIGHT
+    assert (pred == ref_pred).all()
+
+
 def test_set_conv_tile_errors(eng18):
     assert eng18._lib.mpx_set_conv_tile(eng18._h, 999, 0) == -1
     assert eng18._lib.mpx_set_conv_tile(eng18._h, 1, 17) == -1

@@ -81,3 +81,25 @@ def test_bn_is_eval_mode_running_stats():
     scale = sd["bn1.weight"] / torch.sqrt(sd["bn1.running_var"] + 1e-5)
     manual = (manual - sd["bn1.running_mean"].view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + sd["bn1.bias"].view(1, -1, 1, 1)
     assert torch.allclose(y, manual, atol=1e-5)
+
+
+def test_trained_cifar_layers_fixture_pins_conv_bn_relu():
+    """tests/golden/trained_layers_cifar_resnet56.npz: four trained 64->64 3x3 conv+BN pairs of the reference's
+    shipped CIFAR ResNet-56 checkpoint (read with weights_only=True by make_trained_layers_golden.py) and the
+    conv+BN+ReLU outputs torch produced when the fixture was written; the oracle's layer op must reproduce them."""
+    import os
+    import numpy as np
+    from network_interpretation_imagenet_amd import synth
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_layers_cifar_resnet56.npz")
+    g = np.load(path)
+    sd = synth.transplant_trained_layers(synth.make_state_dict("resnet18"), path)
+    gen = torch.Generator().manual_seed(56)
+    x = torch.randn(2, 64, 56, 56, generator=gen).clamp_min(-0.5) * 1.5
+    pick = torch.randperm(2 * 64 * 56 * 56, generator=gen)[:4096]
+    assert (pick.numpy() == g["sample_index"]).all()
+    for n, conv in enumerate(["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"]):
+        y = R._conv_bn(sd, x, conv, 1, 1, True)
+        got = y.reshape(-1)[pick].numpy()
+        assert np.abs(got - g["expect%d" % n]).max() <= 2e-5 * max(1.0, np.abs(g["expect%d" % n]).max())
+    # trained statistics differ from the synthetic initialisation the other tests use
+    assert g["bn1_running_var"].min() < 0.01 and g["bn0_running_var"].max() > 5
