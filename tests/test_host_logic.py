@@ -83,6 +83,41 @@ def test_pack_conv_weights(mpx_lib, cin, cout, k):
     assert (hi[:cout] == scaled.astype(np.float32).astype(np.float16)).all()
 
 
+def test_pack_f16f8_byte_plane(mpx_lib):
+    """mpx_pack_conv_weights_ex(MPX_PRECISION_F16F8): same fp16 hi plane; the second plane holds, per 32 K elements,
+    [e4m3(W_hi / 4) x 32 | e4m3(W_lo * 512) x 32] -- checked against torch's e4m3fn conversion (round to nearest even)."""
+    rng = np.random.default_rng(3)
+    cin, cout, k = 64, 64, 3
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
+    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
+          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2, cout).astype(np.float32)]
+    d = _desc(cin, cout, k)
+    hi, lo, sc, sh = _pack(mpx_lib, d, w, bn)
+    hi8 = np.zeros((d.cout_pad, d.k_packed), dtype=np.uint16)
+    p8 = np.zeros_like(hi8)
+    sc8, sh8 = np.zeros_like(sc), np.zeros_like(sh)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = mpx_lib.mpx_pack_conv_weights_ex(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5, 1,
+                                          p(hi8), p(p8), p(sc8), p(sh8))
+    assert rc == 0
+    assert (hi8.view(np.float16) == hi).all() and (sc8 == sc).all() and (sh8 == sh).all()
+    planes = p8.view(np.uint8).reshape(d.cout_pad, d.k_packed // 32, 64)
+    want_h8 = (torch.from_numpy(hi[:cout].astype(np.float32)) * 0.25).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
+    pow2 = np.round(np.log2(s / sc[:cout].astype(np.float64)))                       # per-cout weight exponent
+    scaled = np.ldexp(w.transpose(0, 2, 3, 1).reshape(cout, -1), pow2.astype(np.int32)[:, None]).astype(np.float32)
+    rem = scaled - hi[:cout].astype(np.float32)                                       # exact in fp32
+    want_l8 = (torch.from_numpy(rem) * 512.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got_h8 = planes[:cout, :, :32].reshape(cout, -1)
+    got_l8 = planes[:cout, :, 32:].reshape(cout, -1)
+    # +0 and -0 are both fine for a zero remainder
+    assert ((got_h8 == want_h8) | ((got_h8 & 0x7f) == 0) & ((want_h8 & 0x7f) == 0)).all()
+    assert ((got_l8 == want_l8) | ((got_l8 & 0x7f) == 0) & ((want_l8 & 0x7f) == 0)).all()
+    assert (planes[cout:] == 0).all()
+    assert mpx_lib.mpx_pack_conv_weights_ex(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5, 7,
+                                            p(hi8), p(p8), p(sc8), p(sh8)) == -1
+
+
 def test_pack_fc(mpx_lib):
     rng = np.random.default_rng(1)
     w = rng.standard_normal((1000, 512)).astype(np.float32)
