@@ -195,7 +195,7 @@ def main():
             achieved = flops_per_batch * batches_profiled / (conv_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(args.arch, batch),
-                        "kernel": "conv_f16x3_kernel", "launches": conv_n,
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,
                         "other_kernels_ms_per_batch": {k: v / max(batches_profiled, 1) for k, v in prof["ms"].items() if k != "conv"}}

@@ -3,6 +3,7 @@
 #include "../../include/mpx.h"
 #include "mpx_kernels.h"
 #include "mpx_conv8.h"
+#include "mpx_conv3p.h"
 
 #include <algorithm>
 #include <cmath>
@@ -263,6 +264,46 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     return 0;
 }
 
+// Rows of the largest input patch any TP-pixel tile of an HxH map needs (mpx_conv3p.h), rounded up to 16.
+int patch_rows_needed(int H, int TP) {
+    const int W = H, PW = W + 2, PIMG = (H + 2) * PW, howo = H * W;
+    auto pb = [&](long long m) { const long long n = m / howo, rem = m % howo; return n * PIMG + (rem / W) * PW + rem % W; };
+    long long worst = 0;
+    for (long long m0 = 0; m0 < (long long)TP * howo; m0 += TP) {      // the pattern repeats after lcm(TP, H*W) pixels
+        const long long r = pb(m0 + TP - 1) - pb(m0) + 2 * PW + 3;
+        worst = r > worst ? r : worst;
+    }
+    return (int)((worst + 15) / 16 * 16);
+}
+
+constexpr int kLdsLimit = 160 * 1024;
+
+// 3x3 stride-1 layers whose patch fits the LDS: the patch kernel (tile id 6)
+template <class PC>
+bool patch_fits(const mpx_conv_desc& d) {
+    if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.cin % 64 != 0 || d.hin != d.hout) return false;
+    const int rows = patch_rows_needed(d.hin, PC::TP);
+    return rows <= PC::MAX_PATCH_ROWS && PC::lds_bytes(rows) <= kLdsLimit;
+}
+
+bool patch_eligible(const mpx_conv_desc& d) {
+    return d.cout <= 64 ? patch_fits<PatchTile1>(d) : patch_fits<PatchTile0>(d);
+}
+
+template <class PC>
+int launch_conv_patch(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipStream_t st) {
+    p.n_tiles_c = (p.cout + PC::TC - 1) / PC::TC;
+    if (p.n_tiles_c * PC::TC > d.cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    p.patch_rows = patch_rows_needed(d.hin, PC::TP);
+    const int lds = PC::lds_bytes(p.patch_rows);
+    const int n_tiles_p = (p.M + PC::TP - 1) / PC::TP;
+    const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
+    if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    hipLaunchKernelGGL(conv3x3p_f16x3_kernel<PC>, dim3((unsigned)nblocks), dim3(PC::NT), lds, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 template <class Cfg>
 int launch_conv_tile8(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;
@@ -279,9 +320,11 @@ int launch_conv_tile8(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st
 // batch 2048: cout <= 64 layers take a 64-row tile (no zero-padded MFMA rows); of the rest, the 128x128 tile
 // with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound epilogue overlaps the
 // other's K loop) and wide 3x3 layers keep the 128x256 tile (fewest L2 bytes per FLOP; 7 % faster in the
-// network although the isolated layer bench prefers 128x128).  Every tile stays selectable.
+// network although the isolated layer bench prefers 128x128); the stride-1 ones whose input patch fits the LDS run
+// the patch kernel (mpx_conv3p.h, tile id 6).  Every tile stays selectable.
 int default_tile(const mpx_conv_desc& d) {
-    if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;
+    if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;       // (the patch kernel is 10 % slower than tile 1 on 64->64 in the network)
+    if (patch_eligible(d)) return 6;                      // 3x3 stride 1 on 28x28 / 14x14 maps: -10..12 % against tile 0
     return d.ksize == 3 ? 0 : 2;
 }
 
@@ -321,6 +364,8 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
             default: return launch_conv_tile8<ConvTile2>(h, p, L.d.cout_pad, st);
         }
     }
+    if (L.tile == 6)
+        return L.d.cout <= 64 ? launch_conv_patch<PatchTile1>(h, p, L.d, st) : launch_conv_patch<PatchTile0>(h, p, L.d, st);
     switch (L.tile) {
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
@@ -472,6 +517,10 @@ int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_eng
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile1::LDS);
@@ -532,7 +581,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile >= CONV_NUM_TILES) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 6 || (tile >= CONV_NUM_TILES && tile != 6)) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile == 6 && (h->fmt || !patch_eligible(L.d)))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;
     return 0;
 }

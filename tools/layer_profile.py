@@ -22,6 +22,12 @@ img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
 seg = torch.from_numpy(synth.grid_segments()).to(dev)
 onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
 labels = torch.zeros(batch, dtype=torch.int32, device=dev)
+if os.environ.get("MPX_TILE_PATCH"):      # tool-only override: patch kernel (tile 6) wherever it is eligible
+    for i, d in enumerate(eng.layers):
+        try:
+            eng.set_conv_tile(i, 6)
+        except Exception:
+            pass
 if os.environ.get("MPX_TILE_C64"):      # tool-only override: one tile variant on every cout <= 64 conv
     for i, d in enumerate(eng.layers):
         if d.cout <= 64:
