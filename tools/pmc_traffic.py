@@ -11,7 +11,7 @@ import os
 import sys
 
 
-def total(path, counter, sub="conv_f16x3"):
+def total(path, counter, sub="_f16x3_kernel"):      # conv_f16x3_kernel and conv3x3p_f16x3_kernel
     s, n = 0.0, 0
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
@@ -31,7 +31,7 @@ fetch = f * 1024 / nb
 write = w * 1024 / nb
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) --kernel-trace -- python3 tools/layer_profile.py "
-              "%s %d; conv_f16x3_kernel launches only, per forward batch of %d masked images" % (arch, batch, batch),
+              "%s %d; conv launches only (conv_f16x3_kernel, conv3x3p_f16x3_kernel), per forward batch of %d masked images" % (arch, batch, batch),
     "arch": arch,
     "forward_batch": batch,
     "launches_per_batch": launches,
