@@ -287,7 +287,7 @@ bool patch_fits(const mpx_conv_desc& d) {
 }
 
 bool patch_eligible(const mpx_conv_desc& d) {
-    return d.cout <= 64 ? patch_fits<PatchTile1>(d) : patch_fits<PatchTile0>(d);
+    return d.cout <= 64 ? patch_fits<PatchTile1>(d) : (patch_fits<PatchTile0>(d) || patch_fits<PatchTile2>(d));
 }
 
 template <class PC>
@@ -364,8 +364,10 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
             default: return launch_conv_tile8<ConvTile2>(h, p, L.d.cout_pad, st);
         }
     }
-    if (L.tile == 6)
-        return L.d.cout <= 64 ? launch_conv_patch<PatchTile1>(h, p, L.d, st) : launch_conv_patch<PatchTile0>(h, p, L.d, st);
+    if (L.tile == 6) {
+        if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
+        return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
+    }
     switch (L.tile) {
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
@@ -520,6 +522,8 @@ int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_eng
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
     if (e == hipSuccess)

@@ -26,20 +26,23 @@ namespace mpx {
 
 template <int TC_, int TP_, int NWR_, int NWC_, int XJP_, int PPS_>
 struct PatchCfg {
-    typedef ConvCfg<TC_, TP_, NWR_, NWC_, 3, 3, 1> Base;     // weight ring geometry (3 stages), one workgroup per CU
     static constexpr int TC = TC_, TP = TP_, NWR = NWR_, NWC = NWC_;
     static constexpr int XJP = XJP_;      // patch pieces (16 rows x 2 planes) a wave moves per chunk
     static constexpr int PPS = PPS_;      // pieces it issues per step, in taps 0 .. XJP/PPS-1 (must end by tap 5, see full_step)
     static_assert(XJP_ % PPS_ == 0 && XJP_ / PPS_ <= 6, "patch pieces must be issued in taps 0..5");
-    static constexpr int NW = Base::NW, NT = Base::NT;
+    static constexpr int NW = NWR * NWC, NT = 64 * NW;
+    static constexpr int CF = TC / NWR / 16, PF = TP / NWC / 16;         // 16x16 fragments per wave
+    static constexpr int WSTAGE = TC * 128;                                // weight stage: [hi TC x 64 B][lo TC x 64 B], 3-deep ring
+    static constexpr int WJ = TC / 16 / NW;                                // weight pieces per wave per plane
+    static constexpr int LW = 2 * WJ;                                      // DMA instructions per wave per weight stage
+    static_assert((TC / 16) % NW == 0 && (TC / NWR) % 16 == 0 && (TP / NWC) % 16 == 0, "tile shape");
     static constexpr int MAX_PATCH_ROWS = 16 * NW * XJP;
-    static constexpr int LW = Base::LW;
     static constexpr int wait_at(int tap) {                   // vmcnt at the top of the step of `tap` (see full_step)
         return LW + pp(tap + 8) + pp(tap + 7);
     }
     static constexpr int pp(int t) { return (t % 9) < XJP / PPS ? 2 * PPS : 0; }      // patch DMA instructions of the step of tap t
     static int lds_bytes(int patch_rows) {
-        const int ring = 3 * Base::WSTAGE + 2 * patch_rows * 128 + NW * 1024;      // + one 1-KiB dump piece per wave
+        const int ring = 3 * WSTAGE + 2 * patch_rows * 128 + NW * 1024;      // + one 1-KiB dump piece per wave
         const int epi = TP * TC * 4;
         return ring > epi ? ring : epi;
     }
@@ -49,9 +52,8 @@ template <class C>
 __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename C::Base B;
     constexpr int TC = C::TC, TP = C::TP, NW = C::NW, NT = C::NT, XJP = C::XJP;
-    constexpr int CF = B::CF, PF = B::PF, WJ = B::WJ, WSTAGE = B::WSTAGE;
+    constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, WSTAGE = C::WSTAGE;
     constexpr int OFF_WHI = 0, OFF_WLO = TC * 64;
     constexpr int XBASE = 3 * WSTAGE;
 
@@ -334,5 +336,6 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
 
 typedef PatchCfg<128, 256, 2, 4, 4, 1> PatchTile0;    // cout >= 128: 8 waves, patch <= 512 rows
 typedef PatchCfg<64, 256, 1, 4, 8, 2> PatchTile1;     // cout = 64: 4 waves side by side, patch <= 512 rows
+typedef PatchCfg<128, 192, 2, 4, 3, 1> PatchTile2;    // 7x7 maps: 192 pixels = 3.9 images, patch <= 384 rows
 
 }  // namespace mpx

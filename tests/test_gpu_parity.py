@@ -236,7 +236,8 @@ def test_trained_layers_end_to_end_scores(eng18_trained):
 
 
 @pytest.mark.parametrize("batch", [1, 3, 11])
-@pytest.mark.parametrize("name", ["layer1.0.conv2", "layer1.2.conv2", "layer2.1.conv2", "layer2.3.conv2", "layer3.5.conv2", "layer3.22.conv2"])
+@pytest.mark.parametrize("name", ["layer1.0.conv2", "layer1.2.conv2", "layer2.1.conv2", "layer2.3.conv2", "layer3.5.conv2", "layer3.22.conv2",
+                                  "layer4.1.conv2", "layer4.2.conv2"])
 def test_conv_patch_kernel(eng101, name, batch):
     """Tile id 6 = the 3x3 patch kernel (csrc/mpx_conv3p.h: input patch staged once per 32-channel chunk, taps are LDS
     row offsets), ragged batches so that tiles start anywhere in an image and the last tile is partial."""
@@ -246,7 +247,7 @@ def test_conv_patch_kernel(eng101, name, batch):
 
 
 def test_conv_patch_kernel_eligibility(eng101):
-    for name in ("layer1.0.conv1", "layer2.0.conv2", "layer4.1.conv2", "conv1"):       # 1x1, stride 2, 7x7 map (patch too large), stem
+    for name in ("layer1.0.conv1", "layer2.0.conv2", "layer4.0.conv2", "conv1"):       # 1x1, stride 2, stride 2, stem
         i = _layer_index(eng101, name)
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 6) == -1
         assert eng101.conv_tile(i) != 6
