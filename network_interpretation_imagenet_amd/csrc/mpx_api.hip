@@ -11,6 +11,7 @@
 #include <initializer_list>
 #include <new>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -324,8 +325,11 @@ int launch_conv_tile8(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st
 // the patch kernel (mpx_conv3p.h, tile id 6).  Every tile stays selectable.
 int default_tile(const mpx_conv_desc& d) {
     if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;       // (the patch kernel is 10 % slower than tile 1 on 64->64 in the network)
-    if (patch_eligible(d)) return 6;                      // 3x3 stride 1 on 28x28 / 14x14 maps: -10..12 % against tile 0
-    return d.ksize == 3 ? 0 : 2;
+    if (patch_eligible(d)) return 6;                      // 3x3 stride 1 on 28x28 / 14x14 / 7x7 maps: -10..18 % against tile 0
+    if (d.ksize == 3) return 0;
+    // expanding 1x1 layers (short K, long epilogue): four waves per SIMD cover the epilogue better, -2..4 % in the
+    // network; the reducing ones (long K) gain nothing from it
+    return (d.stride == 1 && d.cout > d.cin) ? 7 : 2;
 }
 
 int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
@@ -360,7 +364,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         switch (L.tile) {
             case 0: return launch_conv_tile8<ConvTile0>(h, p, L.d.cout_pad, st);
             case 1: case 4: return launch_conv_tile8<ConvTile1>(h, p, L.d.cout_pad, st);
-            case 5: return launch_conv_tile8<ConvTile5>(h, p, L.d.cout_pad, st);
+            case 5: return launch_conv_tile8<ConvTile5>(h, p, L.d.cout_pad, st);      // (6, 7 -> 2)
             default: return launch_conv_tile8<ConvTile2>(h, p, L.d.cout_pad, st);
         }
     }
@@ -373,6 +377,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
         case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+        case 7: return launch_conv_tile<ConvTile7>(h, p, L.d.cout_pad, st);
         case 4: return launch_conv_tile<ConvTile4>(h, p, L.d.cout_pad, st);
         default: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
     }
@@ -515,6 +520,8 @@ int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_eng
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
@@ -585,7 +592,7 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 6 || (tile >= CONV_NUM_TILES && tile != 6)) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 7) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
     if (tile == 6 && (h->fmt || !patch_eligible(L.d)))
         return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;

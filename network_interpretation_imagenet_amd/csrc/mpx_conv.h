@@ -412,6 +412,10 @@ typedef ConvCfg<128, 128, 2, 2, 2, 2> ConvTile2;   // 4 waves, 2-deep rings, 64 
 typedef ConvCfg<128, 128, 2, 2, 2, 3> ConvTile3;   // as tile 2 with a 3-deep X ring (80 KB): measured 5-11 % slower (2 x 80 KB no longer co-reside)
 typedef ConvCfg<64, 192, 1, 4, 2, 2> ConvTile4;    // cout <= 64: 64 KB LDS, 2 workgroups / CU
 typedef ConvCfg<64, 128, 2, 2, 2, 2, 3> ConvTile5; // cout <= 64: 48 KB LDS, 3 workgroups / CU
-constexpr int CONV_NUM_TILES = 6;
+constexpr int CONV_NUM_TILES = 6;                  // ids 0..5; 6 = the 3x3 patch kernel (mpx_conv3p.h)
+// id 7: the 128x128 tile cut into 8 waves of 32 cout x 64 pixels: 124 VGPRs, so two workgroups = 16 waves per CU (4 per
+// SIMD).  Each wave issues half the LDS-DMA pieces and half the MFMAs of a tile-2 wave; with four waves per SIMD one
+// wave's DMA issue and barrier waits are covered by three others.
+typedef ConvCfg<128, 128, 4, 2, 2, 2, 4> ConvTile7;
 
 }  // namespace mpx

@@ -195,7 +195,7 @@ def test_conv_layers_resnet101(eng101, name):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv3", "layer2.0.conv2", "layer3.5.conv2", "layer4.2.conv3"])
 def test_conv_every_tile_variant(eng101, name, tile):
     """Each kernel variant (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""

@@ -74,12 +74,13 @@ def main():
                 _lib.check(eng._h, rc, "mpx_conv_bn_act")
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = int(os.environ.get("F8_SUSTAIN", "5"))       # thousands of launches: steady-state (power-limited) timing
             e0.record()
-            for _ in range(5):
+            for _ in range(nrep):
                 eng._lib.mpx_conv_bn_act(eng._h, i, ptr(xh), ptr(x8), ptr(rh), ptr(r8), ptr(oh), ptr(o8), None, batch, st)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+            ms = e0.elapsed_time(e1) / nrep
             if os.environ.get("F8_NOREF"):
                 fl = 2.0 * batch * d.hout * d.hout * d.cout * d.cin * d.ksize * d.ksize
                 print("%-6s %-22s %4d->%-4d k%d B=%d: %.4f ms  %.1f TFLOP/s" % (precision, name, d.cin, d.cout, d.ksize, batch, ms, fl / ms / 1e9))

@@ -28,6 +28,10 @@ if os.environ.get("MPX_TILE_PATCH"):      # tool-only override: patch kernel (ti
             eng.set_conv_tile(i, 6)
         except Exception:
             pass
+if os.environ.get("MPX_TILE_1X1"):      # tool-only override: one tile variant on every 1x1 conv with cout >= 128
+    for i, d in enumerate(eng.layers):
+        if d.ksize == 1 and d.cout >= 128:
+            eng.set_conv_tile(i, int(os.environ["MPX_TILE_1X1"]))
 if os.environ.get("MPX_TILE_C64"):      # tool-only override: one tile variant on every cout <= 64 conv
     for i, d in enumerate(eng.layers):
         if d.cout <= 64:

@@ -47,7 +47,7 @@ for i, d in enumerate(eng.layers):
     want = y.permute(0, 2, 3, 1)
     dxh, dxl = xh.to(dev), xl.to(dev)
     drh, drl = (rh.to(dev), rl.to(dev)) if rh is not None else (None, None)
-    for tile in range(7):
+    for tile in range(8):
         if tile == 6 and eng._lib.mpx_set_conv_tile(eng._h, i, 6) != 0:
             continue                                    # patch kernel: eligible layers only
         eng.set_conv_tile(i, tile)
