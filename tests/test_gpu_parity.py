@@ -435,7 +435,7 @@ def test_resnet18_vs_live_oracle_noise_image(eng18):
     assert (p_u8 == ref_pred).all() and (p_f32 == ref_pred).all()
 
 
-@pytest.mark.parametrize("arch", ["resnet34", "resnet50"])
+@pytest.mark.parametrize("arch", ["resnet34", "resnet50", "resnet152"])
 def test_other_depths_vs_live_oracle(mpx_lib, arch):
     """The remaining torchvision ResNet topologies the reference's `-a` flag can name (BasicBlock 3-4-6-3 and
     Bottleneck 3-4-6-3): 6 masks against the reference-style CPU loop."""
