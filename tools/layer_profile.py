@@ -28,6 +28,21 @@ if os.environ.get("MPX_TILE_PATCH"):      # tool-only override: patch kernel (ti
             eng.set_conv_tile(i, 6)
         except Exception:
             pass
+if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with classes k1exp k1red k1s2 k3s2 c64k1 c64k3 stem
+    rules = dict(r.split(":") for r in os.environ["MPX_TILE_RULES"].split(","))
+    for i, d in enumerate(eng.layers):
+        if d.cin == 3:
+            cls = "stem"
+        elif d.cout <= 64:
+            cls = "c64k1" if d.ksize == 1 else "c64k3"
+        elif d.ksize == 3:
+            cls = "k3s2" if d.stride == 2 else "k3s1"
+        elif d.stride == 2:
+            cls = "k1s2"
+        else:
+            cls = "k1exp" if d.cout > d.cin else "k1red"
+        if cls in rules:
+            eng.set_conv_tile(i, int(rules[cls]))
 if os.environ.get("MPX_TILE_1X1"):      # tool-only override: one tile variant on every 1x1 conv with cout >= 128
     for i, d in enumerate(eng.layers):
         if d.ksize == 1 and d.cout >= 128:
