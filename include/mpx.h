@@ -57,23 +57,7 @@ typedef struct mpx_conv_desc {
  * replaces: models.__dict__[args.arch](pretrained=True); model.cuda(); model.eval()
  *           (generate_gp_training_data_imagenet.py:579-580,159).  Allocates the whole workspace
  *           (input staging for max_batch masked images, activation planes, logits) once. */
-int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out);      /* = mpx_create_ex(..., MPX_PRECISION_F16X3, ...) */
-
-/* Arithmetic of the conv stack (the reference computes in fp32; the tolerance on the score is 1e-4):
- *   MPX_PRECISION_F16X3  W_hi.X_lo + W_lo.X_hi + W_hi.X_hi on the fp16 MFMA pipe, activations stored as two fp16
- *                        planes: scores within ~1.5e-6 of the fp32 loop.
- *   MPX_PRECISION_F16F8  W_hi.X_hi on the fp16 pipe, the two correction products on the block-scaled fp8 (e4m3)
- *                        MFMA; activations stored as an fp16 plane + a byte plane [l8 x 32 | h8 x 32] per 32
- *                        channels (same bytes): 2/3 of the MFMA cycles, ~1e-5 relative per layer.
- *                        EXPERIMENTAL: only mpx_conv_bn_act (layers > 0) runs on such an engine; the other kernels
- *                        return MPX_E_STATE.  Measured 9-13 % faster on the MFMA-heavy layers only, because the conv
- *                        kernel is bound by LDS-DMA issue rather than by MFMA cycles, so it was not carried
- *                        through K0 / pools / forward.
- * The plane pointers of mpx_conv_bn_act carry the format of the engine they are used with. */
-#define MPX_PRECISION_F16X3 0
-#define MPX_PRECISION_F16F8 1
-int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_engine** out);
-int mpx_precision(const mpx_engine* h);
+int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out);
 int mpx_destroy(mpx_engine* h);
 const char* mpx_last_error(const mpx_engine* h);   /* "" if none; valid until next call */
 int mpx_max_batch(const mpx_engine* h);
@@ -112,12 +96,6 @@ int mpx_get_conv_tile(const mpx_engine* h, int i);
 int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma,
                           const float* beta, const float* mean, const float* var, float eps,
                           uint16_t* w_hi, uint16_t* w_lo, float* scale, float* shift);
-/* The same for either precision: with MPX_PRECISION_F16F8 `w_lo` receives the byte plane, per 32 K elements
- * [e4m3(W_hi / 4) x 32 | e4m3(W_lo * 512) x 32] (same size as the fp16 plane). */
-int mpx_pack_conv_weights_ex(const mpx_conv_desc* d, const float* w, const float* gamma, const float* beta,
-                             const float* mean, const float* var, float eps, int precision, uint16_t* w_hi,
-                             uint16_t* w_lo, float* scale, float* shift);
-
 /* ---- K0: mask-apply + normalise ----------------------------------------------------------
  * replaces: transforms.ToTensor + Normalize (generate_gp_training_data_imagenet.py:598-599),
  *           the per-segment pixel-mask build (:234-237), `input[0].numpy().copy() * mask`

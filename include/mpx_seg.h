@@ -12,8 +12,10 @@
  * greedy pass over sorted edges.  It is not a fallback of anything in mpx.h.
  *
  * Pinned bit-exactly against scikit-image 0.18.3 on the committed vectors (tests/golden/felzenszwalb_skimage0183.npz,
- * written by tests/golden/make_felzenszwalb_golden.py); edges of EXACTLY equal weight are taken in index order
- * here (right, down, down-right, up-right; row-major), where NumPy's unstable argsort leaves the order open.
+ * written by tests/golden/make_felzenszwalb_golden.py).  Edges are built in the order right, down, down-right,
+ * up-right (row-major within each) and sorted by weight; edges of EXACTLY equal weight come out in the order NumPy's
+ * generic (unstable) quicksort leaves them, which mpx_seg.cpp's argsort_introsort reproduces step by step
+ * (partitions of >= 17 elements, median of 3, insertion sort below) -- not in index order.
  */
 #ifndef MPX_SEG_H
 #define MPX_SEG_H

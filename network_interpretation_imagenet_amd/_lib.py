@@ -34,8 +34,6 @@ _fp = C.POINTER(C.c_float)
 # name -> (restype, argtypes); must list every symbol include/mpx.h declares
 SIGNATURES = {
     "mpx_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
-    "mpx_create_ex": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
-    "mpx_precision": (_i, [_vp]),
     "mpx_destroy": (_i, [_vp]),
     "mpx_last_error": (C.c_char_p, [_vp]),
     "mpx_max_batch": (_i, [_vp]),
@@ -47,7 +45,6 @@ SIGNATURES = {
     "mpx_set_conv_tile": (_i, [_vp, _i, _i]),
     "mpx_get_conv_tile": (_i, [_vp, _i]),
     "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
-    "mpx_pack_conv_weights_ex": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_maxpool3x3s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

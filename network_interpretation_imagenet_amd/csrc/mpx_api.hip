@@ -2,7 +2,6 @@
 // launch sequencing.  Compiled for gfx950 only:  hipcc --offload-arch=gfx950 -shared -fPIC.
 #include "../../include/mpx.h"
 #include "mpx_kernels.h"
-#include "mpx_conv8.h"
 #include "mpx_conv3p.h"
 
 #include <algorithm>
@@ -57,7 +56,6 @@ struct ProfRec {
 
 struct mpx_engine {
     int arch = 0, max_batch = 0, device = 0;
-    int fmt = 0;            // MPX_PRECISION_F16X3 (0) or MPX_PRECISION_F16F8 (1): activation / weight plane format
     bool bottleneck = false;
     int feat = 0;
     std::vector<ConvLayer> convs;
@@ -110,25 +108,6 @@ void set_name(char* dst, const std::string& s) {
 int default_tile(const mpx_conv_desc& d);
 
 // torchvision ResNet topology (models/resnet.py, un-vendored): conv list and op list.
-// e4m3fn (OCP): 1-4-3, bias 7, largest finite 448, no infinities; round to nearest even, saturating
-uint8_t f32_to_e4m3(float f) {
-    if (f != f) return 0x7f;
-    const uint8_t sgn = std::signbit(f) ? 0x80 : 0;
-    const float a = std::fabs(f);
-    if (a >= 448.f) return sgn | 0x7e;
-    if (a < 0.015625f) {                                    // below 2^-6: subnormals, spacing 2^-9
-        const int q = (int)std::nearbyint(a * 512.f);       // 0..8 (8 = the smallest normal, code 0x08)
-        return sgn | (uint8_t)q;
-    }
-    int e;
-    const float m = std::frexp(a, &e);                      // a = m * 2^e, m in [0.5, 1)
-    e -= 1;                                                 // a = (2m) * 2^e, 2m in [1, 2)
-    int q = (int)std::nearbyint((2.f * m - 1.f) * 8.f);
-    if (q == 8) { q = 0; e += 1; }
-    if (e > 8 || (e == 8 && q > 6)) return sgn | 0x7e;
-    return sgn | (uint8_t)(((e + 7) << 3) | q);
-}
-
 int build_topology(mpx_engine* h) {
     int depths[4];
     switch (h->arch) {
@@ -305,18 +284,6 @@ int launch_conv_patch(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipS
     return 0;
 }
 
-template <class Cfg>
-int launch_conv_tile8(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
-    p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;
-    if (p.n_tiles_c * Cfg::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
-    const int n_tiles_p = (p.M + Cfg::TP - 1) / Cfg::TP;
-    const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
-    if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
-    hipLaunchKernelGGL(conv_f16f8_kernel<Cfg>, dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
-    MPX_HIP(h, hipGetLastError());
-    return 0;
-}
-
 // Default variant per layer, from tools/tile_sweep.sh and in-network tools/layer_profile.py runs on MI355X at
 // batch 2048: cout <= 64 layers take a 64-row tile (no zero-padded MFMA rows); of the rest, the 128x128 tile
 // with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound epilogue overlaps the
@@ -346,7 +313,6 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     if (L.is_stem) {
         // padded NHWC4 staging: a (ky) tap is one 64-B run of 8 pixels x 4 channels, no bounds to check
         p.x_hi = h->in_hi; p.x_lo = h->in_lo;
-        p.x_lo_split = h->fmt ? (int)((size_t)h->max_batch * MPX_IMG_PAD * MPX_IMG_PAD * 4) : 0;
         p.hin = MPX_IMG_PAD; p.win = MPX_IMG_PAD; p.pix_stride = 4;
         p.kh = kStemK; p.kw = 1; p.stride = 2; p.pad = 0; p.k_per_tap = 32;
     } else {
@@ -360,14 +326,6 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
     p.M = (int)M;
     ProfScope ps(h, st, OP_CONV, i);
-    if (h->fmt) {       // f16f8: the 32x32-block kernels exist for tiles 0, 1, 2, 5 (3 -> 2, 4 -> 1)
-        switch (L.tile) {
-            case 0: return launch_conv_tile8<ConvTile0>(h, p, L.d.cout_pad, st);
-            case 1: case 4: return launch_conv_tile8<ConvTile1>(h, p, L.d.cout_pad, st);
-            case 5: return launch_conv_tile8<ConvTile5>(h, p, L.d.cout_pad, st);      // (6, 7 -> 2)
-            default: return launch_conv_tile8<ConvTile2>(h, p, L.d.cout_pad, st);
-        }
-    }
     if (L.tile == 6) {
         if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
@@ -391,15 +349,7 @@ extern "C" {
 int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma, const float* beta,
                           const float* mean, const float* var, float eps, uint16_t* w_hi, uint16_t* w_lo,
                           float* scale, float* shift) {
-    return mpx_pack_conv_weights_ex(d, w, gamma, beta, mean, var, eps, MPX_PRECISION_F16X3, w_hi, w_lo, scale, shift);
-}
-
-int mpx_pack_conv_weights_ex(const mpx_conv_desc* d, const float* w, const float* gamma, const float* beta,
-                             const float* mean, const float* var, float eps, int precision, uint16_t* w_hi,
-                             uint16_t* w_lo, float* scale, float* shift) {
     if (!d || !w || !w_hi || !w_lo || !scale || !shift) return MPX_E_ARG;
-    if (precision != MPX_PRECISION_F16X3 && precision != MPX_PRECISION_F16F8) return MPX_E_ARG;
-    uint8_t* w8 = (uint8_t*)w_lo;       // f16f8: per 32 K elements [W_h8 x 32 | W_l8 x 32]
     const int cin = d->cin, cout = d->cout, k = d->ksize, K = d->k_packed;
     const bool stem = (cin == 3);
     if (stem ? (k != kStemK || K != kStemK * 32) : (K != k * k * cin || K % 32 != 0)) return MPX_E_ARG;
@@ -426,13 +376,7 @@ int mpx_pack_conv_weights_ex(const mpx_conv_desc* d, const float* w, const float
             const half_t hi = (half_t)sv;
             const half_t lo = (half_t)(sv - (float)hi);
             ph[kk] = half_bits(hi);
-            if (precision == MPX_PRECISION_F16F8) {
-                uint8_t* row8 = w8 + ((size_t)co * K + (size_t)(kk >> 5) * 32) * 2;
-                row8[kk & 31] = f32_to_e4m3((float)hi * F8_WHI_SCALE);
-                row8[32 + (kk & 31)] = f32_to_e4m3((sv - (float)hi) * F8_WLO_SCALE);
-            } else {
-                pl[kk] = half_bits(lo);
-            }
+            pl[kk] = half_bits(lo);
         };
         if (stem) {
             for (int ky = 0; ky < k; ++ky)
@@ -458,18 +402,11 @@ int mpx_pack_conv_weights_ex(const mpx_conv_desc* d, const float* w, const float
 }
 
 int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
-    return mpx_create_ex(arch_id, max_batch, device, MPX_PRECISION_F16X3, out);
-}
-
-int mpx_precision(const mpx_engine* h) { return h ? h->fmt : MPX_E_ARG; }
-
-int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_engine** out) {
     if (!out || max_batch <= 0) return MPX_E_ARG;
     *out = nullptr;
-    if (precision != MPX_PRECISION_F16X3 && precision != MPX_PRECISION_F16F8) return MPX_E_ARG;
     mpx_engine* h = new (std::nothrow) mpx_engine();
     if (!h) return MPX_E_NOMEM;
-    h->arch = arch_id; h->max_batch = max_batch; h->device = device; h->fmt = precision;
+    h->arch = arch_id; h->max_batch = max_batch; h->device = device;
     int rc = build_topology(h);
     if (rc) { delete h; return rc; }
     hipError_t e = hipSetDevice(device);
@@ -531,14 +468,6 @@ int mpx_create_ex(int arch_id, int max_batch, int device, int precision, mpx_eng
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile1::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16f8_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
     *out = h;
     return 0;
@@ -576,7 +505,7 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamm
     const size_t n = (size_t)L.d.cout_pad * L.d.k_packed;
     std::vector<uint16_t> hi(n), lo(n);
     std::vector<float> sc(L.d.cout_pad), sh(L.d.cout_pad);
-    int rc = mpx_pack_conv_weights_ex(&L.d, w, L.is_fc ? nullptr : gamma, beta, mean, var, eps, h->fmt, hi.data(), lo.data(), sc.data(), sh.data());
+    int rc = mpx_pack_conv_weights(&L.d, w, L.is_fc ? nullptr : gamma, beta, mean, var, eps, hi.data(), lo.data(), sc.data(), sh.data());
     if (rc) return fail(h, rc, "pack failed for %s", L.d.name);
     MPX_HIP(h, hipSetDevice(h->device));
     MPX_HIP(h, hipMemcpy(L.w_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
@@ -593,7 +522,7 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
     if (tile > 7) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
-    if (tile == 6 && (h->fmt || !patch_eligible(L.d)))
+    if (tile == 6 && !patch_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;
     return 0;
@@ -615,7 +544,6 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
                              const uint8_t* onoff, int M, int S, const float mean[3], const float std[3], int slot0,
                              float* out_f32_nchw, void* stream) {
     if (!h) return MPX_E_ARG;
-    if (h->fmt) return fail(h, MPX_E_STATE, "%s: f16f8 engines run mpx_conv_bn_act only (experimental precision, DESIGN.md 5)", "mask_apply_normalize");
     if ((img_u8_hwc == nullptr) == (img_f32_chw == nullptr))
         return fail(h, MPX_E_ARG, "mask_apply_normalize: exactly one of img_u8_hwc / img_f32_chw must be given");
     if (!seg || !onoff || M <= 0 || S <= 0) return fail(h, MPX_E_ARG, "mask_apply_normalize: null input or empty M/S");
@@ -645,7 +573,6 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
 int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* res_hi, const void* res_lo,
                     void* out_hi, void* out_lo, float* out_f32, int B, void* stream) {
     if (!h) return MPX_E_ARG;
-    if (h->fmt && i == 0) return fail(h, MPX_E_STATE, "conv_bn_act: the stem of an f16f8 engine has no staging kernel yet");
     if (i < 0 || i >= (int)h->convs.size() || B <= 0) return fail(h, MPX_E_ARG, "conv_bn_act: bad layer index or batch");
     const ConvLayer& L = h->convs[i];
     if (L.is_stem) {
@@ -665,7 +592,6 @@ int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, 
 int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B, int hin,
                      int c, void* stream) {
     if (!h) return MPX_E_ARG;
-    if (h->fmt) return fail(h, MPX_E_STATE, "%s: f16f8 engines run mpx_conv_bn_act only (experimental precision, DESIGN.md 5)", "maxpool3x3s2");
     if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hin <= 0 || (hin & 1) || c <= 0 || (c & 7))
         return fail(h, MPX_E_ARG, "maxpool3x3s2: bad arguments (hin even, c multiple of 8)");
     MPX_HIP(h, hipSetDevice(h->device));
@@ -682,7 +608,6 @@ int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* 
 int mpx_global_avgpool(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B, int hw,
                        int c, void* stream) {
     if (!h) return MPX_E_ARG;
-    if (h->fmt) return fail(h, MPX_E_STATE, "%s: f16f8 engines run mpx_conv_bn_act only (experimental precision, DESIGN.md 5)", "global_avgpool");
     if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hw <= 0 || c <= 0 || (c & 7))
         return fail(h, MPX_E_ARG, "global_avgpool: bad arguments (c multiple of 8)");
     MPX_HIP(h, hipSetDevice(h->device));
@@ -711,7 +636,6 @@ int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* l
 int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred, float* logits_out, int B,
                 void* stream) {
     if (!h) return MPX_E_ARG;
-    if (h->fmt) return fail(h, MPX_E_STATE, "%s: f16f8 engines run mpx_conv_bn_act only (experimental precision, DESIGN.md 5)", "forward");
     if (!label || !score || !pred || B <= 0) return fail(h, MPX_E_ARG, "forward: null pointer or empty batch");
     if (B > h->max_batch) return fail(h, MPX_E_STATE, "forward: B=%d exceeds max_batch=%d", B, h->max_batch);
     if (mpx_weights_complete(h) != 1) return fail(h, MPX_E_STATE, "forward: weights not loaded for every layer");

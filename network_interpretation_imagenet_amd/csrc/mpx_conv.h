@@ -61,7 +61,6 @@ struct ConvParams {
     int M;                   // B*ho*wo output pixels
     int n_tiles_c;           // cout_pad / TC
     int relu;
-    int x_lo_split;          // f16f8 stem only: bytes between the l8 and h8 byte planes of the staging (0 = interleaved)
     int patch_rows;          // mpx_conv3p.h only: allocated rows of an input patch (multiple of 16)
 };
 

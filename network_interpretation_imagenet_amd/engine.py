@@ -54,15 +54,7 @@ def rank_segments(segments):
 class MaskedForwardEngine:
     """One engine per process per GPU (one RCCL rank).  `arch` is the reference's `-a/--arch`."""
 
-    PRECISIONS = {"f16x3": 0, "f16f8": 1}
-
-    def __init__(self, arch="resnet101", max_batch=512, device=None, precision="f16x3"):
-        """precision: "f16x3" (three fp16 MFMA products, scores within ~1.5e-6 of fp32; the product path) or
-        "f16f8" (EXPERIMENTAL: main product fp16, the two correction products on the block-scaled fp8 MFMA; such
-        an engine only runs mpx_conv_bn_act -- see include/mpx.h and tools/f8_conv_check.py)."""
-        if precision not in self.PRECISIONS:
-            raise ValueError("precision must be one of %s, got %r" % (sorted(self.PRECISIONS), precision))
-        self.precision = precision
+    def __init__(self, arch="resnet101", max_batch=512, device=None):
         if arch not in ARCH_IDS:
             raise ValueError("unsupported arch %r (torchvision ResNets only: %s)" % (arch, sorted(ARCH_IDS)))
         if not torch.cuda.is_available():
@@ -72,7 +64,7 @@ class MaskedForwardEngine:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.max_batch = int(max_batch)
         h = C.c_void_p()
-        rc = self._lib.mpx_create_ex(ARCH_IDS[arch], self.max_batch, self.device.index, self.PRECISIONS[precision], C.byref(h))
+        rc = self._lib.mpx_create(ARCH_IDS[arch], self.max_batch, self.device.index, C.byref(h))
         if rc != 0:
             raise MpxError("mpx_create(%s, max_batch=%d) failed rc=%d" % (arch, max_batch, rc))
         self._h = h

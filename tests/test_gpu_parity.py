@@ -253,56 +253,6 @@ def test_conv_patch_kernel_eligibility(eng101):
         assert eng101.conv_tile(i) != 6
 
 
-def _planes_f16f8(x):
-    """f32[..., C] -> (hi f16, byte plane u8[..., C/32, 64] = per 32 channels [e4m3(lo * 2^11) x 32 | e4m3(hi) x 32])"""
-    hi = x.to(torch.float16)
-    lo = ((x - hi.float()) * 2048.0).clamp(-448, 448).to(torch.float8_e4m3fn)
-    h8 = hi.float().clamp(-448, 448).to(torch.float8_e4m3fn)
-    shp = x.shape[:-1] + (x.shape[-1] // 32, 32)
-    return hi.contiguous(), torch.cat([lo.view(torch.uint8).reshape(shp), h8.view(torch.uint8).reshape(shp)], dim=-1).contiguous()
-
-
-def _value_f16f8(hi, p8):
-    l8 = p8[..., :32].contiguous().view(torch.float8_e4m3fn).float().reshape(hi.shape)
-    return hi.float() + l8 / 2048.0
-
-
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 5])
-@pytest.mark.parametrize("name", ["layer1.0.conv2", "layer1.0.conv3", "layer2.0.conv2", "layer3.1.conv3"])
-def test_conv_f16f8_experimental(mpx_lib, dev, name, tile):
-    """The experimental precision (fp16 main product + block-scaled fp8 correction products, csrc/mpx_conv8.h)
-    through mpx_conv_bn_act: ~1e-5 relative (3 mantissa bits on terms that are 2^-11 of the result, and outputs
-    stored as fp16 + e4m3 remainder); bound 4e-5.  Everything else on such an engine refuses to run."""
-    sd = synth.make_state_dict("resnet50")
-    eng = MaskedForwardEngine("resnet50", max_batch=3, device=0, precision="f16f8").load_state_dict(sd)
-    try:
-        i = _layer_index(eng, name)
-        d = eng.layers[i]
-        eng.set_conv_tile(i, tile)
-        g = torch.Generator().manual_seed(i)
-        x = torch.randn(3, d.hin, d.hin, d.cin, generator=g).clamp_min(-0.5) * 1.5
-        res = torch.randn(3, d.hout, d.hout, d.cout, generator=g) if d.residual else None
-        xh, x8 = _planes_f16f8(x.to(dev))
-        rh, r8 = _planes_f16f8(res.to(dev)) if res is not None else (None, None)
-        oh = torch.full((3, d.hout, d.hout, d.cout), float("nan"), dtype=torch.float16, device=dev)
-        o8 = torch.zeros(3, d.hout, d.hout, d.cout // 32, 64, dtype=torch.uint8, device=dev)
-        rc = eng._lib.mpx_conv_bn_act(eng._h, i, _p(xh), _p(x8), _p(rh), _p(r8), _p(oh), _p(o8), None, 3, eng._stream())
-        _lib.check(eng._h, rc, "mpx_conv_bn_act")
-        torch.cuda.synchronize()
-        got = _value_f16f8(oh, o8).cpu().double()
-        want = _conv_reference(sd, d, _value_f16f8(xh, x8).cpu().double().permute(0, 3, 1, 2),
-                               _value_f16f8(rh, r8).cpu().double().permute(0, 3, 1, 2) if res is not None else None).permute(0, 2, 3, 1)
-        assert not torch.isnan(got).any()
-        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
-        assert err <= 4e-5, "%s tile %d: %.3e" % (name, tile, err)
-        assert eng._lib.mpx_precision(eng._h) == 1
-        labels = torch.zeros(1, dtype=torch.int32, device=dev)
-        with pytest.raises(MpxError):
-            eng.forward(1, labels)
-    finally:
-        eng.close()
-
-
 def test_set_conv_tile_errors(eng18):
     assert eng18._lib.mpx_set_conv_tile(eng18._h, 999, 0) == -1
     assert eng18._lib.mpx_set_conv_tile(eng18._h, 1, 17) == -1

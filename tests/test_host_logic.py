@@ -26,6 +26,41 @@ def test_library_exports_every_declared_symbol(mpx_lib):
         assert getattr(mpx_lib, name) is not None
 
 
+def test_build_stamp_covers_every_source(tmp_path):
+    """The .so staleness stamp hashes every file the library is built from (glob of csrc/*.h, csrc/*.hip and
+    include/mpx.h) plus the compiler flags: an edit to ANY kernel header, or a flag change, must invalidate it --
+    the GPU box receives the prebuilt .so and would otherwise run code that is not in the tree."""
+    import shutil
+    import __graft_entry__ as g
+    names = {os.path.basename(f) for f in g.lib_sources()}
+    assert {"mpx_api.hip", "mpx_kernels.h", "mpx_conv.h", "mpx_conv3p.h", "mpx.h"} <= names
+    csrc = os.path.join(ROOT, "network_interpretation_imagenet_amd", "csrc")
+    for f in os.listdir(csrc):                       # every header mpx_api.hip can include is hashed
+        if f.endswith((".h", ".hip")):
+            assert f in names, f
+    root = tmp_path / "tree"
+    shutil.copytree(csrc, root / "network_interpretation_imagenet_amd" / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    lib = str(root / "libfake.so")
+    open(lib, "wb").close()
+    src = g.lib_sources(str(root))
+    with open(lib + ".sha256", "w") as fh:
+        fh.write(g._source_hash(src, g.HIPCC_FLAGS) + "\n")
+    assert not g._stale(lib, src, g.HIPCC_FLAGS)
+    for victim in ("mpx_conv3p.h", "mpx_kernels.h", "mpx.h"):
+        path = [f for f in src if os.path.basename(f) == victim][0]
+        before = open(path).read()
+        with open(path, "a") as fh:
+            fh.write("// touched\n")
+        assert g._stale(lib, src, g.HIPCC_FLAGS), victim
+        with open(path, "w") as fh:
+            fh.write(before)
+        assert not g._stale(lib, src, g.HIPCC_FLAGS)
+    assert g._stale(lib, src, g.HIPCC_FLAGS + ["-DX"])                  # flags are part of the stamp
+    (root / "network_interpretation_imagenet_amd" / "csrc" / "mpx_new_kernel.h").write_text("// new\n")
+    assert g._stale(lib, g.lib_sources(str(root)), g.HIPCC_FLAGS)      # a new header is picked up by the glob
+
+
 def test_null_engine_calls_fail_cleanly(mpx_lib):
     assert mpx_lib.mpx_num_convs(None) == -1
     assert mpx_lib.mpx_forward(None, None, None, None, None, 1, None) == -1
@@ -81,41 +116,6 @@ def test_pack_conv_weights(mpx_lib, cin, cout, k):
     # split-fp16 keeps >= 21 bits of every weight relative to the channel maximum's exponent
     assert np.abs(rec - scaled).max() <= 1024 * 2.0 ** -21
     assert (hi[:cout] == scaled.astype(np.float32).astype(np.float16)).all()
-
-
-def test_pack_f16f8_byte_plane(mpx_lib):
-    """mpx_pack_conv_weights_ex(MPX_PRECISION_F16F8): same fp16 hi plane; the second plane holds, per 32 K elements,
-    [e4m3(W_hi / 4) x 32 | e4m3(W_lo * 512) x 32] -- checked against torch's e4m3fn conversion (round to nearest even)."""
-    rng = np.random.default_rng(3)
-    cin, cout, k = 64, 64, 3
-    w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
-    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
-          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2, cout).astype(np.float32)]
-    d = _desc(cin, cout, k)
-    hi, lo, sc, sh = _pack(mpx_lib, d, w, bn)
-    hi8 = np.zeros((d.cout_pad, d.k_packed), dtype=np.uint16)
-    p8 = np.zeros_like(hi8)
-    sc8, sh8 = np.zeros_like(sc), np.zeros_like(sh)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = mpx_lib.mpx_pack_conv_weights_ex(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5, 1,
-                                          p(hi8), p(p8), p(sc8), p(sh8))
-    assert rc == 0
-    assert (hi8.view(np.float16) == hi).all() and (sc8 == sc).all() and (sh8 == sh).all()
-    planes = p8.view(np.uint8).reshape(d.cout_pad, d.k_packed // 32, 64)
-    want_h8 = (torch.from_numpy(hi[:cout].astype(np.float32)) * 0.25).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
-    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
-    pow2 = np.round(np.log2(s / sc[:cout].astype(np.float64)))                       # per-cout weight exponent
-    scaled = np.ldexp(w.transpose(0, 2, 3, 1).reshape(cout, -1), pow2.astype(np.int32)[:, None]).astype(np.float32)
-    rem = scaled - hi[:cout].astype(np.float32)                                       # exact in fp32
-    want_l8 = (torch.from_numpy(rem) * 512.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
-    got_h8 = planes[:cout, :, :32].reshape(cout, -1)
-    got_l8 = planes[:cout, :, 32:].reshape(cout, -1)
-    # +0 and -0 are both fine for a zero remainder
-    assert ((got_h8 == want_h8) | ((got_h8 & 0x7f) == 0) & ((want_h8 & 0x7f) == 0)).all()
-    assert ((got_l8 == want_l8) | ((got_l8 & 0x7f) == 0) & ((want_l8 & 0x7f) == 0)).all()
-    assert (planes[cout:] == 0).all()
-    assert mpx_lib.mpx_pack_conv_weights_ex(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5, 7,
-                                            p(hi8), p(p8), p(sc8), p(sh8)) == -1
 
 
 def test_pack_fc(mpx_lib):
