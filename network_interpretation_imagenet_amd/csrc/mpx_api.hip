@@ -75,6 +75,9 @@ struct mpx_engine {
     std::vector<ProfRec> prof_pool;
     int prof_used = 0;
     hipStream_t prof_stream = nullptr;
+#ifdef MPX_DIAG
+    unsigned long long* stamps = nullptr;
+#endif
 };
 
 namespace {
@@ -325,6 +328,9 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     if (M > 0x7fffffffLL || (long long)B * p.hin * p.win > 0x7fffffffLL)
         return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
     p.M = (int)M;
+#ifdef MPX_DIAG
+    p.stamps = h->stamps;
+#endif
     ProfScope ps(h, st, OP_CONV, i);
     if (L.tile == 6) {
         if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
@@ -713,6 +719,15 @@ int mpx_profile_collect(mpx_engine* h, double ms_by_kind[4], long long launches_
     h->prof_used = 0;
     return 0;
 }
+
+#ifdef MPX_DIAG
+// diagnostic build only (not declared in include/mpx.h): DEV u64[8 * workgroups of the next conv launches]
+int mpx_debug_set_stamps(mpx_engine* h, void* dev_buf) {
+    if (!h) return MPX_E_ARG;
+    h->stamps = (unsigned long long*)dev_buf;
+    return 0;
+}
+#endif
 
 double mpx_flops_per_forward(const mpx_engine* h) {
     if (!h) return 0.0;

@@ -62,7 +62,27 @@ struct ConvParams {
     int n_tiles_c;           // cout_pad / TC
     int relu;
     int patch_rows;          // mpx_conv3p.h only: allocated rows of an input patch (multiple of 16)
+#ifdef MPX_DIAG
+    unsigned long long* stamps;   // diagnostic build only (tools/probes/conv_timeline.py): 8 u64 per workgroup
+#endif
 };
+
+// Diagnostic build (-DMPX_DIAG, never the product library): wave 0 of every workgroup keeps s_memtime stamps of its
+// phases in SGPRs and writes them, with the CU it ran on, to p.stamps at the end.
+#ifdef MPX_DIAG
+#define MPX_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPX_STAMP_WRITE(p, t_start, t_pro, t_kend, t_epi)                                                        \
+    if ((p).stamps && threadIdx.x == 0) {                                                                         \
+        unsigned long long* o_ = (p).stamps + (size_t)blockIdx.x * 8;                                             \
+        o_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                                   \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   /* HW_ID | XCC_ID */    \
+        o_[1] = t_start; o_[2] = t_pro; o_[3] = t_kend; o_[4] = t_epi; o_[5] = __builtin_amdgcn_s_memtime();        \
+        o_[6] = __builtin_amdgcn_s_memrealtime();                                                                  \
+    }
+#else
+#define MPX_STAMP(var)
+#define MPX_STAMP_WRITE(p, a, b, c, d)
+#endif
 
 template <int TC_, int TP_, int NWR_, int NWC_, int NSW_, int NSX_, int MINB_ = 2>
 struct ConvCfg {
@@ -107,6 +127,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, XJ = C::XJ, WSTAGE = C::WSTAGE, XSTAGE = C::XSTAGE, XBASE = C::XBASE;
     constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = 0, OFF_XLO = TP * 64;     // within a W stage / an X stage
 
+    MPX_STAMP(t_start);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     }
     wait_vmcnt<C::WAIT_PROLOGUE>();
     __builtin_amdgcn_s_barrier();
+    MPX_STAMP(t_pro);
     Frags fa, fb;
     load_frags(0, 0, fa);
 
@@ -329,6 +351,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         mfma_all(fa);
     }
     wait_vmcnt<0>();                // the trailing dummy DMAs must land before the epilogue reuses the LDS
+    MPX_STAMP(t_kend);
 
     // ---- epilogue ----
     // Phase 0: prefetch the residual rows this thread will own in phase 2 (whole 16-B chunks).
@@ -367,6 +390,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         }
     }
     __syncthreads();
+    MPX_STAMP(t_epi);
     // Phase 2: one thread = 8 consecutive channels of one pixel.
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
             __builtin_nontemporal_store(ol, (h8*)(p.y_lo + o));
         }
     }
+    MPX_STAMP_WRITE(p, t_start, t_pro, t_kend, t_epi);
 #endif
 }
 

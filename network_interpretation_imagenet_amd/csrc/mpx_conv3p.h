@@ -57,6 +57,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
     constexpr int OFF_WHI = 0, OFF_WLO = TC * 64;
     constexpr int XBASE = 3 * WSTAGE;
 
+    MPX_STAMP(t_start);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
     stage_w(2, 0, 2);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    MPX_STAMP(t_pro);
     Frags fa, fb;
     set_baddr(0);
 #pragma unroll
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
         ws = full_step(std::integral_constant<int, 8>{}, c + 1, ws, fb, fa);
     }
     wait_vmcnt<0>();
+    MPX_STAMP(t_kend);
 
     // ---- epilogue (as mpx_conv.h) ------------------------------------------------------------------------------------
     constexpr int GPP = TC / 8;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
         }
     }
     __syncthreads();
+    MPX_STAMP(t_epi);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int pl = it * PPI + prow2;
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
         __builtin_nontemporal_store(oh, (h8*)(p.y_hi + o));
         __builtin_nontemporal_store(ol, (h8*)(p.y_lo + o));
     }
+    MPX_STAMP_WRITE(p, t_start, t_pro, t_kend, t_epi);
 #endif
 }
 

@@ -462,6 +462,127 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
         eng.close()
 
 
+def _bench_shape_forward(eng, imgs_u8, seg, onoff, labels, dev):
+    """Stage n_img x n_mask masks exactly as bench.py's step() does (image j -> slots [j*n_mask, (j+1)*n_mask)) and
+    run ONE forward over the whole batch.  -> (score f32[n_img, n_mask], pred i32[n_img, n_mask]) numpy."""
+    n_img, n_mask = onoff.shape[:2]
+    seg_d = torch.from_numpy(seg).to(dev)
+    for j in range(n_img):
+        eng.stage_masks(torch.from_numpy(imgs_u8[j]).to(dev), seg_d, torch.from_numpy(onoff[j]).to(dev), j * n_mask)
+    label_rows = torch.from_numpy(np.repeat(np.asarray(labels, dtype=np.int32), n_mask)).to(dev)
+    score, pred = eng.forward(n_img * n_mask, label_rows)
+    torch.cuda.synchronize()
+    return score.view(n_img, n_mask).cpu().numpy(), pred.view(n_img, n_mask).cpu().numpy()
+
+
+def test_cfg3_benched_shape_resnet101_2048_vs_oracle(mpx_lib, dev):
+    """BASELINE configs[2] at the shape bench.py times: ResNet-101, forward batch 2048 = 4 different images x 512
+    masks in one launch sequence (n_first descriptor rebasing, the 2-GiB num_records clamp, the patch kernel's
+    q0 / PIMG arithmetic over thousands of images and the multi-image slot staging all run at this size only).
+    First and last mask of every image against the reference-style batch-1 CPU loop (<= 2e-5); every one of the
+    2048 scores bit-equal to the same masks through a max_batch=32 engine (different tile rounds and descriptors)."""
+    arch, n_img, n_mask = "resnet101", 4, 512
+    sd = synth.make_state_dict(arch)
+    imgs = synth.make_images(n_img, seed=1234, kind="noise")
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(n_img * n_mask, 196, seed=4321).reshape(n_img, n_mask, 196)
+    small = MaskedForwardEngine(arch, max_batch=32, device=0).load_state_dict(sd)
+    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0).load_state_dict(sd)
+    try:
+        labels = [small.predict(imgs[j])[0] for j in range(n_img)]
+        score, pred = _bench_shape_forward(big, imgs, seg, onoff, labels, dev)
+        assert np.isfinite(score).all()
+        worst = 0.0
+        for j in range(n_img):
+            x = scorer.to_tensor_normalize(imgs[j])
+            assert scorer.base_prediction(sd, arch, x) == labels[j]
+            pick = [0, n_mask - 1]
+            ref, ref_pred = scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[j][pick], labels[j])
+            worst = max(worst, float(np.abs(score[j][pick] - ref).max()))
+            assert (pred[j][pick] == ref_pred).all()
+            _o, s_small, p_small = small.score_masks(imgs[j], seg, onoff[j], labels[j])     # 16 forwards of 32
+            assert (s_small == score[j]).all() and (p_small == pred[j]).all(), "image %d differs between batch 2048 and batch 32" % j
+        print("cfg-3 benched shape: max|d| vs CPU loop on 8 slots %.3e" % worst)
+        assert worst <= SCORE_TOL_TIGHT
+    finally:
+        big.close()
+        small.close()
+
+
+def test_cfg2_resnet18_256_masks_per_image_in_one_batch(mpx_lib, dev):
+    """BASELINE configs[1]: ResNet-18, 256 masks per image, 8 of the 32 images in one forward batch of 2048 (the
+    bench's `--arch resnet18 --masks 256 --images-per-forward 8`).  16 slots (first and last mask of each image)
+    against the CPU loop; the rest by slot invariance: an engine of max_batch 64 must give the same bits."""
+    arch, n_img, n_mask = "resnet18", 8, 256
+    sd = synth.make_state_dict(arch)
+    imgs = synth.make_images(n_img, seed=99, kind="noise")
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(n_img * n_mask, 196, seed=17).reshape(n_img, n_mask, 196)
+    onoff[3, 100] = onoff[3, 7]                    # duplicate rows inside an image
+    small = MaskedForwardEngine(arch, max_batch=64, device=0).load_state_dict(sd)
+    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0).load_state_dict(sd)
+    try:
+        labels = [small.predict(imgs[j])[0] for j in range(n_img)]
+        score, pred = _bench_shape_forward(big, imgs, seg, onoff, labels, dev)
+        assert score[3, 100] == score[3, 7]
+        worst = 0.0
+        for j in range(n_img):
+            x = scorer.to_tensor_normalize(imgs[j])
+            pick = [0, n_mask - 1]
+            ref, ref_pred = scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[j][pick], labels[j])
+            worst = max(worst, float(np.abs(score[j][pick] - ref).max()))
+            assert (pred[j][pick] == ref_pred).all()
+            _o, s_small, p_small = small.score_masks(imgs[j], seg, onoff[j], labels[j])
+            assert (s_small == score[j]).all() and (p_small == pred[j]).all()
+        print("cfg-2 shape: max|d| vs CPU loop on 16 slots %.3e" % worst)
+        assert worst <= SCORE_TOL_TIGHT
+    finally:
+        big.close()
+        small.close()
+
+
+def test_cfg5_bo_window_sweep_on_hip_engine_vs_oracle_loop(mpx_lib, dev, golden_dir):
+    """BASELINE configs[4] / SURVEY 8 f1: the reference-named BO objective on the HIP engine.  On the committed
+    felzenszwalb fixture (scikit-image 0.18.3 labels of the blobs224 picture) api.sample_loss([f], ...) for EVERY
+    f in [0, int(0.6*S)] must agree with the oracle's literal loop (bayesian_active_learning_imagenet.py:173-198:
+    np.unique(segments)[f:f+k] -> mask[segments == v] = 1 -> input*mask -> batch-1 forward -> softmax[label]);
+    then bo.bayesian_optimisation runs end to end (BayesianOptimization.py:99-192 signature) and every y it
+    collected is the table entry of its x."""
+    import random
+    from network_interpretation_imagenet_amd import api, bo
+    arch = "resnet101"
+    sd = synth.make_state_dict(arch)
+    g = np.load(os.path.join(golden_dir, "felzenszwalb_skimage0183.npz"))
+    img, seg = g["blobs224/image"], g["blobs224/labels"].astype(np.int64)
+    S = len(np.unique(seg))
+    ub = scorer.bo_upper_bound(S)
+    x = scorer.to_tensor_normalize(img)
+    label = scorer.base_prediction(sd, arch, x)
+    eng = MaskedForwardEngine(arch, max_batch=256, device=0).load_state_dict(sd)
+    api.configure(eval_img_index=1, segmenter=lambda _img_show: seg, mask_dir=None, seed=None)
+    try:
+        loader = [(x[None], torch.tensor([label]))]
+        got = np.array([api.sample_loss([f], loader, eng, None) for f in range(ub + 1)], dtype=np.float32)
+        assert got.dtype == np.float32
+        want = np.zeros(ub + 1, dtype=np.float32)
+        for f in range(ub + 1):
+            mask = scorer.window_mask_u8(seg, f)
+            want[f], _pred = scorer.score_one(sd, arch, scorer.apply_mask(x, mask), label)
+            assert (api.superpixel_mask(f) == mask * 255).all()                     # bayesian...:224-276
+        err = float(np.abs(got - want).max())
+        print("cfg-5: S=%d, %d windows, max|d| vs literal loop %.3e, score range %.4f..%.4f" % (S, ub + 1, err, want.min(), want.max()))
+        assert err <= SCORE_TOL_TIGHT
+        assert api.sample_loss(np.array([12.9]), loader, eng, None) == got[12]      # L-BFGS-B floats truncate (:283)
+        xp, yp = bo.bayesian_optimisation(n_iters=10, sample_loss=api.sample_loss, val_loader=loader, nn_model=eng,
+                                          criterion=None, bounds=np.array([[0, ub]]), n_pre_samples=3, rng=random.Random(5))
+        assert xp.shape == (13, 1) and yp.shape == (13,)
+        assert ((xp >= 0) & (xp <= ub)).all()
+        assert all(np.float32(y) == got[int(f)] for f, y in zip(xp[:, 0], yp))
+    finally:
+        api.configure(eval_img_index=1, segmenter=None, mask_dir=None, seed=None)
+        eng.close()
+
+
 def test_heatmap_accumulate_exact(eng18, dev, golden_dir):
     """K5 vs the oracle's literal accumulation (integer-valued, so exact)."""
     seg = np.load(os.path.join(golden_dir, "segments_blobs.npz"))["segments"][0].astype(np.int32)
