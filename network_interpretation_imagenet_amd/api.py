@@ -22,13 +22,15 @@ from . import masks
 from .engine import BasePredictionWrong, rank_segments, IMG
 
 __all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
-           "validate", "validate_summed", "validate_summed_many", "score_masks", "default_segmenter",
+           "validate", "validate_gp_superpixel", "validate_summed", "validate_summed_many", "score_masks", "default_segmenter",
+           "jet_heatmap_u8",
            "img_show_u8", "load_images_from_folder", "prepare_training_data", "get_pixel_sorted_mask_label",
            "summed_heatmap_from_folder",
            "BasePredictionWrong", "configure"]
 
 _CONFIG = {"eval_img_index": 1, "num_mask_samples": 100, "segmenter": None, "mask_dir": None, "seed": None}
-_SESSIONS = {}
+_SESSIONS = []          # [(model, val_loader, eval_img_index, session)], most recent last; identity-checked, bounded
+_MAX_SESSIONS = 8
 _LAST = {"session": None}
 
 
@@ -41,7 +43,7 @@ def configure(**kw):
         if k not in _CONFIG:
             raise KeyError("unknown option %r (have %s)" % (k, sorted(_CONFIG)))
         _CONFIG[k] = v
-    _SESSIONS.clear()
+    del _SESSIONS[:]
 
 
 def default_segmenter(img_u8_hwc):
@@ -116,6 +118,13 @@ class SaliencySession:
         _o, score, pred = self.score_windows([f])
         return score[0], int(pred[0])
 
+    def summed_labels(self, firsts, correct):
+        """f64[224,224] = sum over the correct masks of their pixel mask (gp_superpixel_data_imagenet.py:322-323):
+        the engine's K5 heat-map kernel (mpx_heatmap_accumulate) on the mask-vectors of `firsts`."""
+        onoff = masks.windows_onoff(self.num_segments, firsts)
+        pred = np.where(np.asarray(correct, dtype=bool), self.label, -1).astype(np.int32)
+        return self.engine.heatmap(self.seg_rank, onoff, pred, self.label)
+
     def mask_u8(self, first_index):
         """u8[224,224] in {0,255} (`mask*255`, bayesian_active_learning_imagenet.py:276)."""
         return masks.expand_pixel_mask(self.seg_rank, masks.window_onoff(self.num_segments, first_index)) * np.uint8(255)
@@ -133,14 +142,21 @@ def _pick(val_loader, eval_img_index):
 
 
 def _session(val_loader, model, eval_img_index):
-    key = (id(model), id(val_loader), int(eval_img_index))
-    s = _SESSIONS.get(key)
-    if s is None:
-        item = _pick(val_loader, eval_img_index)
-        if item is None:
-            return None
-        s = SaliencySession(model, item[0], item[1])
-        _SESSIONS[key] = s
+    """The cached session of (model, val_loader, eval_img_index).  The cache holds strong references to the model and
+    the loader and compares them with `is` (an id() key could be reused by a NEW object after garbage collection and
+    hand back another dataset's table), and keeps at most _MAX_SESSIONS entries."""
+    idx = int(eval_img_index)
+    for k, (m, l, i, s) in enumerate(_SESSIONS):
+        if m is model and l is val_loader and i == idx:
+            _SESSIONS.append(_SESSIONS.pop(k))
+            _LAST["session"] = s
+            return s
+    item = _pick(val_loader, idx)
+    if item is None:
+        return None
+    s = SaliencySession(model, item[0], item[1])
+    _SESSIONS.append((model, val_loader, idx, s))
+    del _SESSIONS[:-_MAX_SESSIONS]
     _LAST["session"] = s
     return s
 
@@ -217,27 +233,55 @@ def validate(val_loader, model, criterion, eval_img_index, num_mask_samples=None
     return int(correct.sum())
 
 
-def validate_summed(val_loader, model, criterion, eval_img_index, num_mask_samples=None, rng=None):
-    """-> summed_superpixel_labels f64[224,224]: sum over correct masks of the pixel mask
-    (gp_superpixel_data_imagenet.py:322-323,350; equals gp_regression.py:82-94's
-    y[p] = sum_i label_i*mask_i[p]).  The JET heat-map picture is plotting and not produced."""
+_JET_BGR = None
+
+
+def jet_heatmap_u8(summed):
+    """summed f64[H,W] -> u8[H,W,3] (BGR), the picture gp_superpixel_data_imagenet.py:337-343 builds: min-max rescale
+    to u8 (`-= min; /= max; *= 255; astype(np.uint8)`, truncating) then cv2.applyColorMap(..., cv2.COLORMAP_JET).
+    cv2 is not a dependency: the colour map is a 256-entry LUT of the classic piecewise-linear jet,
+    channel(x) = clamp(1.5 - |4x - c|, 0, 1) with c = 3, 2, 1 for R, G, B and x = i/255, rounded to u8.  (PARITY
+    UNPINNED for the exact LUT bytes: OpenCV is absent from this image; the leading table entries 1.5/255, 5.5/255
+    agree with OpenCV's published table.)  A constant map gives 0/0 upstream; here it maps to LUT[0]."""
+    global _JET_BGR
+    if _JET_BGR is None:
+        x = np.arange(256, dtype=np.float64) / 255.0
+        ch = lambda c: np.rint(np.clip(1.5 - np.abs(4.0 * x - c), 0.0, 1.0) * 255.0).astype(np.uint8)
+        _JET_BGR = np.stack([ch(1.0), ch(2.0), ch(3.0)], axis=1)         # B, G, R
+    show = np.array(summed, dtype=np.float64, copy=True)
+    show -= show.min()
+    mx = show.max()
+    if mx > 0:
+        show /= mx
+    show *= 255
+    return _JET_BGR[show.astype(np.uint8)]
+
+
+def validate_gp_superpixel(val_loader, model, criterion, eval_img_index, num_mask_samples=None, rng=None):
+    """-> (summed_superpixel_labels f64[224,224], summed_labels_heatmap u8[224,224,3]), the return of the
+    gp_superpixel flavour of validate() (gp_superpixel_data_imagenet.py:186-350, unpacked by its caller at :617):
+    the sum over the correctly predicted masks of their pixel mask (:322-323; equals gp_regression.py:82-94's
+    y[p] = sum_i label_i*mask_i[p]) and its JET picture (:337-343).  When the unmasked prediction is wrong the
+    reference prints "wrong prediction" and falls off the end of the function (returns None, :351-352): so does this."""
     n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
     try:
         out = _generator_pass(val_loader, model, eval_img_index, n, rng)
     except BasePredictionWrong:
         print("wrong prediction")
-        return np.zeros((IMG, IMG), dtype=np.float64)
+        return None
     if out is None:
-        return np.zeros((IMG, IMG), dtype=np.float64)
+        return None
     s, firsts, correct = out
-    onoff = masks.windows_onoff(s.num_segments, firsts)
-    per_segment = (onoff * correct[:, None].astype(np.uint8)).sum(0).astype(np.float64)
-    return per_segment[s.seg_rank]
+    summed = s.summed_labels(firsts, correct)
+    return summed, jet_heatmap_u8(summed)
+
+
+validate_summed = validate_gp_superpixel      # earlier name of the same entry point
 
 
 def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mask_samples=None, rng=None,
                          workers=4, lookahead=None):
-    """validate_summed for several images of one pass over the loader: {index: f64[224,224] or None}
+    """The heat map of validate_gp_superpixel for several images of one pass over the loader: {index: f64[224,224] or None}
     (None where the unmasked prediction is wrong, the reference's "wrong prediction" branch).
     The CPU segmentation of the next images (segment.SegmenterPool) runs while the GPU scores the
     current one -- the reference segments and scores strictly one after the other
@@ -263,9 +307,7 @@ def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mas
         firsts = masks.draw_first_indices(s.num_segments, n, rng)
         _score, table_pred = s.table()
         correct = np.array([table_pred[f] for f in firsts], dtype=np.int64) == s.label
-        onoff = masks.windows_onoff(s.num_segments, firsts)
-        per_segment = (onoff * correct[:, None].astype(np.uint8)).sum(0).astype(np.float64)
-        out[idx] = per_segment[s.seg_rank]
+        out[idx] = s.summed_labels(firsts, correct)
 
     with segment.SegmenterPool(workers=workers) as pool:
         count = 0

@@ -259,6 +259,17 @@ class MaskedForwardEngine:
                    "mpx_heatmap_accumulate")
         return heat
 
+    def heatmap(self, seg_rank, onoff, pred, label):
+        """Host-array convenience over K5: -> f64[224,224] = sum_m [pred[m] == label] * onoff[m][seg[p]]
+        (counts are integers < 2^24, so the f32 accumulation on the device is exact)."""
+        m = int(np.asarray(onoff).shape[0])
+        heat = torch.zeros(IMG, IMG, dtype=torch.float32, device=self.device)
+        if m:
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+            self.heatmap_accumulate(t(seg_rank, np.int32), t(onoff, np.uint8), t(pred, np.int32),
+                                    torch.full((m,), int(label), dtype=torch.int32, device=self.device), heat)
+        return heat.cpu().numpy().astype(np.float64)
+
     # ---- kernel variants (tuning / tests) ----
     def set_conv_tile(self, layer, tile):
         """Select the conv kernel variant of one layer (index or torchvision name); tile < 0 = default."""

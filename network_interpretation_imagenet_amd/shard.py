@@ -4,7 +4,9 @@ The reference has no distributed code (its --world-size/--dist-url flags are par
 read: generate_gp_training_data_imagenet.py:72-77,572).  Every (image, mask) pair is independent
 (:221-266), so the flattened work index w = img*M + m is cut into P contiguous blocks with no
 data-path collective; the only exchange is ONE all-gather of the per-mask scores (RCCL over xGMI
-when the backend is "nccl", gloo on CPU in the tests).
+when the backend is "nccl", gloo on CPU in the tests).  When the consumer wants the summed heat map of
+an image instead of the scores (gp_superpixel_data_imagenet.py:322-323), every rank accumulates its
+masks with K5 and ONE all-reduce of f32[224*224] (196 KiB) closes the image.
 """
 import torch
 import torch.distributed as dist
@@ -88,3 +90,40 @@ def score_masks_sharded(engine, image, segments, onoff, label, group=None):
     s_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(score)).to(device), m, group)
     p_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(pred)).to(device), m, group)
     return s_all.cpu().numpy(), p_all.cpu().numpy()
+
+
+def all_reduce_heatmap(heat, group=None):
+    """Sum the per-rank partial heat maps in place: ONE all_reduce(SUM) of f32[224,224] per image (RCCL when the
+    tensor is on the GPU, gloo on the CPU).  The partial maps hold integer counts below 2^24, so the f32 sum is exact
+    and independent of the reduction order.  No-op in a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(heat, op=dist.ReduceOp.SUM, group=group)
+    return heat
+
+
+def heatmap_sharded(engine, image, segments, onoff, label, group=None):
+    """Heat map of ONE image with its M mask-vectors split over the ranks (contiguous blocks of the mask axis):
+    each rank scores its block, accumulates sum_m [pred[m] == label] * onoff[m][seg[p]] on its device (K5,
+    engine.heatmap_accumulate) and one all-reduce yields the full f32[224,224] map on every rank -- equal to the
+    single-engine map exactly (integer counts).  `segments` must be a rank map (engine.rank_segments).
+    returns (heat f32[224,224] tensor on the engine's device, n_correct int over all ranks)."""
+    import numpy as np
+    m = int(onoff.shape[0])
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = block(m, rank, world)
+    device = getattr(engine, "device", torch.device("cpu"))
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
+    heat = torch.zeros(224, 224, dtype=torch.float32, device=device)
+    count = torch.zeros(1, dtype=torch.float32, device=device)
+    if hi > lo:
+        _o, _score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+        part = engine.heatmap(segments, onoff[lo:hi], pred, label)            # f64[224,224] on the host, exact
+        heat += torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32)).to(device)
+        count += float((np.asarray(pred) == label).sum())
+    all_reduce_heatmap(heat, group)
+    all_reduce_heatmap(count, group)
+    return heat, int(count.item())

@@ -191,6 +191,10 @@ class FakeEngine:
         s, p = scorer.score_masks_batched(self.sd, self.arch, torch.as_tensor(image), segments, onoff, label, chunk=16)
         return onoff, s.astype(np.float32), p.astype(np.int32)
 
+    def heatmap(self, seg_rank, onoff, pred, label):
+        """The test double's own K5 (the real engine runs mpx_heatmap_accumulate)."""
+        return scorer.summed_superpixel_labels(seg_rank, onoff, np.asarray(pred) == label)
+
 
 @pytest.fixture()
 def coarse_setup(tmp_path):
@@ -259,8 +263,24 @@ def test_api_validate_generators(coarse_setup):
     assert isinstance(n_ok, int) and 0 <= n_ok <= 12
     files = sorted(os.listdir(mask_dir))
     assert len(files) == 12 and sum(f.endswith("_1.png") for f in files) == n_ok
-    summed = api.validate_summed(loader, eng, None, 2)
+    summed, heatmap = api.validate_gp_superpixel(loader, eng, None, 2)     # the 2-tuple gp_superpixel...:350,617 unpacks
     assert summed.shape == (224, 224) and summed.dtype == np.float64
+    assert heatmap.shape == (224, 224, 3) and heatmap.dtype == np.uint8
+    assert (heatmap == api.jet_heatmap_u8(summed)).all()
+    # the picture: min-max -> u8 (truncating) -> JET; literal rescale on a non-constant map + the LUT's anchor colours
+    demo = np.add.outer(np.arange(224.0), 3.0 * np.arange(224.0))
+    show = demo.copy()[:, :, None]
+    show -= show.min()
+    show /= show.max()
+    show *= 255
+    show = show.astype(np.uint8)[:, :, 0]
+    pic = api.jet_heatmap_u8(demo)
+    assert (pic[show == 0] == (128, 0, 0)).all() and (pic[show == 255] == (0, 0, 128)).all()     # BGR: dark blue .. dark red
+    lut = api.jet_heatmap_u8(np.arange(256, dtype=np.float64).reshape(16, 16)).reshape(256, 3)
+    assert (lut[32] == (255, 0, 0)).all() and (lut[128] == (126, 255, 130)).all() and (lut[223] == (0, 0, 255)).all()
+    assert (lut[:, 1].argmax() == 96) and (np.diff(lut[:33, 0].astype(int)) >= 0).all()      # green saturates at 96; blue ramps up first
+    assert (pic == lut[show]).all()
+    assert (api.jet_heatmap_u8(np.zeros((4, 4))) == (128, 0, 0)).all()     # constant map: no 0/0
     # same seed -> same draws: compare with the oracle's literal accumulation
     firsts = masks.draw_first_indices(16, 12, random.Random(5))
     onoff = masks.windows_onoff(16, firsts)
@@ -274,7 +294,7 @@ def test_api_png_wire_format_round_trip(coarse_setup):
     generate_gp_training_data_imagenet.py:490-516) reads them back into the same heat map validate_summed builds."""
     eng, loader, _seg, _label, mask_dir = coarse_setup
     n_ok = api.validate(loader, eng, None, 2)
-    summed = api.validate_summed(loader, eng, None, 2)               # same seed -> same draws
+    summed, _pic = api.validate_summed(loader, eng, None, 2)         # same seed -> same draws
     files, labels = api.load_images_from_folder(str(mask_dir))
     assert len(files) == 12 and sorted(set(labels)) <= ["0", "1"] and labels.count("1") == n_ok
     assert (api.summed_heatmap_from_folder(str(mask_dir)) == summed).all()
@@ -290,7 +310,7 @@ def test_api_png_wire_format_round_trip(coarse_setup):
 def test_api_validate_summed_many_pipelines_segmentation(coarse_setup):
     eng, loader, seg, label, _ = coarse_setup
     loader3 = loader + [loader[1]]
-    one = api.validate_summed(loader3, eng, None, 2, rng=random.Random(9))
+    one, _pic = api.validate_summed(loader3, eng, None, 2, rng=random.Random(9))
     many = api.validate_summed_many(loader3, eng, None, [2], rng=random.Random(9), workers=2)
     assert list(many) == [2] and (many[2] == one).all()
     r = random.Random(9)
@@ -298,7 +318,29 @@ def test_api_validate_summed_many_pipelines_segmentation(coarse_setup):
     assert sorted(both) == [2, 3] and (both[2] == one).all() and both[3].shape == (224, 224)
     bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
     assert api.validate_summed_many(bad, eng, None, [2], workers=1) == {2: None}
+    assert api.validate_gp_superpixel(bad, eng, None, 2) is None           # "wrong prediction": falls off the end upstream
     assert api.validate_summed_many(loader, eng, None, []) == {}
+
+
+def test_session_cache_checks_identity_and_is_bounded():
+    """The session cache compares model and loader by identity on strong references (an id() key can be reused by a
+    new object) and keeps a bounded number of entries."""
+    eng = FakeEngine()
+    x = scorer.to_tensor_normalize(synth.make_images(1)[0])
+    label, _ = eng.predict(x)
+    seg = synth.grid_segments(block=112)              # 4 superpixels
+    api.configure(eval_img_index=1, segmenter=lambda img: seg, mask_dir=None, seed=None)
+    try:
+        loaders = [[(x[None], torch.tensor([label]))] for _ in range(api._MAX_SESSIONS + 3)]
+        first = api._session(loaders[0], eng, 1)
+        assert api._session(loaders[0], eng, 1) is first                   # same objects: cached
+        assert api._session(list(loaders[0]), eng, 1) is not first         # an equal but different loader: new session
+        for l in loaders[1:]:
+            api._session(l, eng, 1)
+        assert len(api._SESSIONS) == api._MAX_SESSIONS
+        assert all(e[0] is eng for e in api._SESSIONS)
+    finally:
+        api.configure(eval_img_index=1, num_mask_samples=100, segmenter=None, mask_dir=None, seed=None)
 
 
 def test_default_segmenter_is_the_native_front_end():

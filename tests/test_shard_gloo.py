@@ -69,6 +69,10 @@ class _TableEngine:
         v = (onoff.astype(np.float64) * w).sum(1)
         return onoff, (np.sin(v) * 0.5 + 0.5).astype(np.float32), (v.astype(np.int64) % 7).astype(np.int32)
 
+    def heatmap(self, seg_rank, onoff, pred, label):
+        per_segment = (onoff * (np.asarray(pred) == label)[:, None]).sum(0).astype(np.float64)
+        return per_segment[seg_rank]
+
 
 def _mask_worker(rank, world, port, m, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -95,3 +99,39 @@ def test_mask_axis_sharding_single_image(tmp_path, m):
     for r in range(2):
         got = np.load(tmp_path / ("m%d.npz" % r))
         assert (got["score"] == want_s).all() and (got["pred"] == want_p).all()
+
+
+def _seg23():
+    idx = np.arange(224) // 10
+    return ((idx[:, None] + idx[None, :]) % 23).astype(np.int32)
+
+
+def _heat_worker(rank, world, port, m, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
+        heat, n_ok = shard.heatmap_sharded(_TableEngine(), None, _seg23(), onoff, 3)
+        np.savez(os.path.join(out_dir, "h%d.npz" % rank), heat=heat.numpy(), n_ok=n_ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m", [40, 5, 1])
+def test_heat_map_all_reduce_two_ranks(tmp_path, m):
+    """per-rank partial heat maps (K5) + ONE all_reduce of f32[224,224] per image = the single-engine
+    heat map, exactly, on every rank."""
+    mp.spawn(_heat_worker, args=(2, _free_port(), m, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(11)
+    onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
+    eng = _TableEngine()
+    _o, _s, pred = eng.score_masks(None, None, onoff, 3)
+    want = eng.heatmap(_seg23(), onoff, pred, 3)
+    single, n_single = shard.heatmap_sharded(eng, None, _seg23(), onoff, 3)
+    assert (single.numpy().astype(np.float64) == want).all() and n_single == int((pred == 3).sum())
+    for r in range(2):
+        got = np.load(tmp_path / ("h%d.npz" % r))
+        assert got["heat"].dtype == np.float32 and (got["heat"].astype(np.float64) == want).all()
+        assert int(got["n_ok"]) == n_single
