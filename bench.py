@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_EVERY = 4               # HIP-event bracketing on every 4th forward batch of the timed region
+F16X3_CEILING_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three MFMA products per algorithmic product
 
 
 def parse():
@@ -61,22 +61,51 @@ def pmc_traffic(arch, batch):
     return None
 
 
-def cpu_baseline(arch, n_masks):
-    """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per
-    superpixel) on this box's host cores, bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_loop(arch, n_masks, threads, seg_block=16):
+    """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per superpixel) -> (fwd/s, s)."""
     from network_interpretation_imagenet_amd import synth
     from oracle import scorer
+    torch.set_num_threads(threads)
     sd = synth.make_state_dict(arch)
     img = synth.make_images(1, kind="noise")[0]
     x = scorer.to_tensor_normalize(img)
-    seg = synth.grid_segments()
-    onoff = synth.random_onoff(n_masks, 196)
+    seg = synth.grid_segments(block=seg_block)
+    onoff = synth.random_onoff(n_masks, int(seg.max()) + 1)
     scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[:1], 0)    # warm the thread pool
     t0 = time.perf_counter()
     scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, 0)
     dt = time.perf_counter() - t0
-    return {"value": n_masks / dt, "unit": "masked-forward-passes/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s)" % (arch, n_masks, dt)}
+    return n_masks / dt, dt
+
+
+def cpu_baseline(arch, n_masks):
+    """the reference-style CPU loop on this box's host cores, bounded samples: the benched arch
+    (`value`, comparable with the GPU line) on all threads, and BASELINE cfg-1 exactly (ResNet-18, 1 image, 64 masks)
+    on all threads and on ONE thread; CPU model and thread count stated."""
+    all_threads = torch.get_num_threads()
+    v, dt = _cpu_loop(arch, n_masks, all_threads)
+    c1_all, dt_all = _cpu_loop("resnet18", 64, all_threads)
+    c1_one, dt_one = _cpu_loop("resnet18", 16, 1)
+    torch.set_num_threads(all_threads)
+    from oracle import resnet_ref
+    gf18 = resnet_ref.flops_per_forward("resnet18") / 1e9
+    return {"value": v, "unit": "masked-forward-passes/s", "cores": all_threads, "kind": "port",
+            "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s)" % (arch, n_masks, dt),
+            "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(),
+            "cfg1_resnet18_1x64": {"all_threads": {"value": c1_all, "threads": all_threads, "seconds": dt_all, "gflops": c1_all * gf18},
+                                   "one_thread": {"value": c1_one, "threads": 1, "seconds": dt_one, "gflops": c1_one * gf18,
+                                                  "sample": "16 of the 64 masks"}}}
 
 
 def main():
@@ -95,12 +124,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
 
     import __graft_entry__ as g
-    if use_dist:            # one builder per node; the others load the finished library
-        if local_rank == 0:
-            g.build()
+    if local_rank == 0:     # one builder per node; the other ranks only load the finished library
+        g.build()
+    if use_dist:
         dist.barrier()
-    g.build()
-    from network_interpretation_imagenet_amd import shard, synth
+    from network_interpretation_imagenet_amd import _lib, shard, synth
+    _lib.load()
     from network_interpretation_imagenet_amd.engine import MaskedForwardEngine
 
     n_img, n_mask, ipf = args.images, args.masks, args.images_per_forward
@@ -127,7 +156,8 @@ def main():
         labels.append(p)
     labels = torch.cat(labels)
     label_rows = labels.view(n_img, 1).expand(n_img, n_mask).contiguous()
-    scores = torch.empty(n_img, n_mask, dtype=torch.float32, device=dev)
+    scores = torch.empty(n_img, n_mask, dtype=torch.float32, device=dev)      # outputs pre-allocated: the step allocates nothing
+    preds = torch.empty(n_img, n_mask, dtype=torch.int32, device=dev)
     total = world * n_img * n_mask
 
     def step(profile):
@@ -142,14 +172,14 @@ def main():
                     engines[k].forward(nb, label_rows[:ipf].view(-1)[:nb].contiguous())
         for f, i0 in enumerate(range(0, n_img, ipf)):
             e, st = engines[f % len(engines)], streams[f % len(engines)]
-            prof = profile and (f % PROFILE_EVERY == 0) and e is eng
+            prof = profile and e is eng
             with torch.cuda.stream(st):
                 if prof:
                     e.profile(True)
                 for j in range(ipf):
                     e.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
-                s, _p = e.forward(batch, label_rows[i0:i0 + ipf].view(-1))
-                scores[i0:i0 + ipf] = s.view(ipf, n_mask)
+                e.forward(batch, label_rows[i0:i0 + ipf].view(-1), score_out=scores[i0:i0 + ipf].view(-1),
+                          pred_out=preds[i0:i0 + ipf].view(-1))
                 if prof:
                     e.profile(False)
         for st in streams:
@@ -166,24 +196,46 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    # the timed region: exactly K steps, nothing but the step inside (no per-kernel events, no allocation); ONE pair of
+    # HIP events on the launch stream brackets it for the GPU-side time
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    prof = {"ms": {}, "launches": {}}
+    ev0.record()
     for _ in range(args.steps):
-        out = step(True)
-        part = eng.collect_profile()        # waits for this step's last recorded event (the pool is bounded)
-        for key in ("ms", "launches"):
-            for k, v in part[key].items():
-                prof[key][k] = prof[key].get(k, 0) + v
+        out = step(False)
+    ev1.record()
     fence()
     dt = time.perf_counter() - t0
+    gpu_ms_timed = ev0.elapsed_time(ev1)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.numel() == total and bool(torch.isfinite(out).all())
+    # per-kernel durations: ONE more step of the same work after the timed region, every launch bracketed by HIP events
+    # on its stream (engine profile pool); bounded to the first 32 forward batches of the step
+    prof = {"ms": {}, "launches": {}}
+    if rank == 0:
+        step_imgs = min(n_img, 32 * ipf)
+        for f, i0 in enumerate(range(0, step_imgs, ipf)):
+            eng.profile(True)
+            for j in range(ipf):
+                eng.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
+            eng.forward(batch, label_rows[i0:i0 + ipf].view(-1), score_out=scores[i0:i0 + ipf].view(-1),
+                        pred_out=preds[i0:i0 + ipf].view(-1))
+            eng.profile(False)
+            part = eng.collect_profile()
+            for key in ("ms", "launches"):
+                for k, v in part[key].items():
+                    prof[key][k] = prof[key].get(k, 0) + v
+        torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
 
     if rank == 0:
         value = total * args.steps / dt
+        cfg_name = {("resnet101", 512, 128): "BASELINE configs[2]" if world == 1 else "BASELINE configs[3] at 8 GPUs",
+                    ("resnet18", 256, 32): "BASELINE configs[1]"}.get((args.arch, n_mask, n_img), "custom")
         conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
         n_conv_layers = len(eng.layers)
         batches_profiled = conv_n / n_conv_layers if n_conv_layers else 0
@@ -197,7 +249,13 @@ def main():
                         "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(args.arch, batch),
                         "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
+                        # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the
+                        # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)
+                        "f16x3_ceiling": F16X3_CEILING_TFLOPS, "frac_of_f16x3_ceiling": achieved / F16X3_CEILING_TFLOPS,
                         "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,
+                        "measured": "HIP events around every launch of one extra step after the timed region (%d forward batches)" % int(batches_profiled),
+                        "conv_ms_per_batch": conv_ms / max(batches_profiled, 1),
+                        "timed_region_gpu_ms_per_batch": gpu_ms_timed / (args.steps * (n_img // ipf)),
                         "other_kernels_ms_per_batch": {k: v / max(batches_profiled, 1) for k, v in prof["ms"].items() if k != "conv"}}
         line = {
             "metric": "masked-forward-passes/sec (224x224, %s)" % args.arch,
@@ -205,7 +263,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
-            "config": {"workload": "%s, %d masks/image x %d images per GPU (BASELINE configs[2]; x%d GPUs)" % (args.arch, n_mask, n_img, world),
+            "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
                        "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "streams": len(engines),
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mpx {
 
@@ -62,6 +63,12 @@ struct ConvParams {
     int n_tiles_c;           // cout_pad / TC
     int relu;
     int patch_rows;          // mpx_conv3p.h only: allocated rows of an input patch (multiple of 16)
+    // DUAL kernels only (a block's last conv with its downsample branch K-concatenated, mpx_api.hip build_fused):
+    // K steps [0, k1/32) read x_* as above; K steps [k1/32, ktot/32) are a 1x1 stride-`stride2` conv over x2_*.
+    const half_t* x2_hi;
+    const half_t* x2_lo;
+    int hin2, win2, pix_stride2, stride2;
+    int k1;
 #ifdef MPX_DIAG
     unsigned long long* stamps;   // diagnostic build only (tools/probes/conv_timeline.py): 8 u64 per workgroup
 #endif
@@ -119,7 +126,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <class C>
+template <class C, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,6 +187,28 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         x_ix0[i] = ox * p.stride - p.pad;
         x_off0[i] = (((n - n_first) * p.hin + x_iy0[i]) * p.win + x_ix0[i]) * p.pix_stride * 2 + src_q * 2;
     }
+    // DUAL: second pixel operand (the block input under the downsample conv): descriptor pair of its own and one
+    // byte offset per X piece (1x1, no padding: only m >= M is out of range)
+    __amdgpu_buffer_rsrc_t x2_rs_hi = x_rs_hi, x2_rs_lo = x_rs_lo;
+    int x2_off0[DUAL ? XJ : 1];
+    if (DUAL) {
+        const int n_img = p.M / howo;
+        const int img2 = p.hin2 * p.win2 * p.pix_stride2;
+        const size_t rem = (size_t)(n_img - n_first) * img2 * 2;
+        const int nrec = rem > 0x7fffffffu ? 0x7fffffff : (int)rem;
+        x2_rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2_hi + (size_t)n_first * img2), 0, nrec, 0x00020000);
+        x2_rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2_lo + (size_t)n_first * img2), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XJ; ++i) {
+            const int m = m0 + (i * NW + wave) * 16 + prow;
+            const int n = m / howo;
+            const int rem2 = m - n * howo;
+            const int oy = rem2 / p.wo;
+            const int ox = rem2 - oy * p.wo;
+            const int off = (((n - n_first) * p.hin2 + oy * p.stride2) * p.win2 + ox * p.stride2) * p.pix_stride2 * 2 + src_q * 2;
+            x2_off0[i] = off | ((p.M - 1 - m) & (int)OOB);
+        }
+    }
     // W rows of this wave: piece (j*NW + wave) of each plane; HALF_W: one piece of one plane
     int w_off[WJ];
 #pragma unroll
@@ -223,6 +252,13 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb + OFF_XHI + d), 16, voff, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sb + OFF_XLO + d), 16, voff, 0, 0, 0);
     };
+    auto stage_x2 = [&](int i, int buf, int cb, bool live) {       // DUAL: channels [cb, cb+32) of the second operand
+        char* sb = smem + XBASE + buf * XSTAGE;
+        const int voff = (x2_off0[DUAL ? i : 0] + cb * 2) | (live ? 0 : (int)OOB);
+        const int d = (i * NW + wave) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rs_hi, MPX_LDS_PTR(sb + OFF_XHI + d), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rs_lo, MPX_LDS_PTR(sb + OFF_XLO + d), 16, voff, 0, 0, 0);
+    };
     f4 acc[CF][PF];
 #pragma unroll
     for (int a = 0; a < CF; ++a)
@@ -230,6 +266,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         for (int b = 0; b < PF; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
     int ky = 0, kx = 0, c0 = 0;     // coordinates of the NEXT step to stage
+    int cb = 0;                     // DUAL: channel offset of the next stage within the second operand
     auto advance = [&]() {      // branch-free (the K step must stay one basic block for the scheduler)
         c0 += 32;
         const bool wc0 = (c0 == p.k_per_tap);
@@ -307,7 +344,8 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     //   then one fragment read of step ks+1 after every second MFMA,
     //   with the DMA groups W(ks+NSW), X(ks+NSX) piece by piece after MFMAs 1, 5, 9, ... (early, so that they have
     //   the rest of the step to land).
-    auto full_step = [&](int ks, const Frags& cur, Frags& nxt) {
+    auto full_step = [&](auto seg_tag, int ks, const Frags& cur, Frags& nxt) {
+        constexpr bool SEGB = decltype(seg_tag)::value;     // this step stages from the second operand (DUAL)
         // own pieces of stage ks+1 landed (younger ones stay in flight), and -- lgkmcnt(0) -- this wave's reads of
         // the slots of step ks returned; the barrier then frees them for W(ks+NSW) and X(ks+NSX)
         __builtin_amdgcn_sched_barrier(0);
@@ -330,22 +368,35 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
             for (int g = 0; g < G; ++g) {
                 if (i == C::DMA_FIRST + 4 * g) {      // early in the step: the pieces need the rest of it to land
                     if (g == 0) stage_w(wslot, ks + NSW);
+                    else if (SEGB) stage_x2(g - 1, xslot, cb, live);
                     else stage_x(g - 1, xslot, ky, kx, c0, live);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        advance();
+        if (SEGB) cb += 32;
+        else advance();
         wslot = nw;
         xslot = nx;
     };
+    typedef std::integral_constant<bool, false> SegA;
+    typedef std::integral_constant<bool, DUAL> SegLast;     // the operand the last K steps stage from
     int ks = 0;
+    if (DUAL) {
+        // steps whose DMA stage (ks + NSX) still belongs to the first operand; the host guarantees that k1/32 - NSX is
+        // even and >= 0, so the fa / fb ping-pong stays in phase
+        const int n_a = (p.k1 >> 5) - NSX;
+        for (; ks < n_a; ks += 2) {
+            full_step(SegA{}, ks, fa, fb);
+            full_step(SegA{}, ks + 1, fb, fa);
+        }
+    }
     for (; ks + 2 < nk; ks += 2) {
-        full_step(ks, fa, fb);
-        full_step(ks + 1, fb, fa);
+        full_step(SegLast{}, ks, fa, fb);
+        full_step(SegLast{}, ks + 1, fb, fa);
     }
     if (ks + 2 == nk) {
-        full_step(ks, fa, fb);
+        full_step(SegLast{}, ks, fa, fb);
         mfma_all(fb);
     } else {
         mfma_all(fa);

@@ -160,13 +160,17 @@ class MaskedForwardEngine:
             self._h, u8, f32, _ptr(seg), _ptr(onoff), int(m), int(s), self._mean, self._std,
             int(slot0), _ptr(out_f32), self._stream()), "mpx_mask_apply_normalize")
 
-    def forward(self, batch, labels, want_logits=False):
+    def forward(self, batch, labels, want_logits=False, score_out=None, pred_out=None):
         """Whole network over the staged slots [0,batch).  labels: device i32[batch].
-        returns (score f32[batch], pred i32[batch][, logits f32[batch,1000]]) on the device."""
-        if labels.dtype != torch.int32 or labels.device != self.device or labels.numel() != batch:
-            raise ValueError("labels must be int32[%d] on %s" % (batch, self.device))
-        score = torch.empty(batch, dtype=torch.float32, device=self.device)
-        pred = torch.empty(batch, dtype=torch.int32, device=self.device)
+        returns (score f32[batch], pred i32[batch][, logits f32[batch,1000]]) on the device; score_out / pred_out
+        (contiguous device tensors of that shape and dtype) receive the results without any allocation."""
+        if labels.dtype != torch.int32 or labels.device != self.device or labels.numel() != batch or not labels.is_contiguous():
+            raise ValueError("labels must be contiguous int32[%d] on %s" % (batch, self.device))
+        for name, t, dt in (("score_out", score_out, torch.float32), ("pred_out", pred_out, torch.int32)):
+            if t is not None and (t.dtype != dt or t.device != self.device or t.numel() != batch or not t.is_contiguous()):
+                raise ValueError("%s must be contiguous %s[%d] on %s" % (name, dt, batch, self.device))
+        score = score_out if score_out is not None else torch.empty(batch, dtype=torch.float32, device=self.device)
+        pred = pred_out if pred_out is not None else torch.empty(batch, dtype=torch.int32, device=self.device)
         logits = torch.empty(batch, NUM_CLASSES, dtype=torch.float32, device=self.device) if want_logits else None
         _lib.check(self._h, self._lib.mpx_forward(self._h, _ptr(labels), _ptr(score), _ptr(pred), _ptr(logits),
                                                   int(batch), self._stream()), "mpx_forward")
