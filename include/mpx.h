@@ -124,6 +124,20 @@ int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo,
                     const void* res_hi, const void* res_lo, void* out_hi, void* out_lo,
                     float* out_f32, int B, void* stream);
 
+/* ---- K1 with the downsample branch fused in ---------------------------------------------------
+ * replaces: `out = self.bn3(self.conv3(out)); identity = self.downsample(x); out += identity; out = self.relu(out)`
+ *           of the first Bottleneck of a stage (torchvision resnet.py, reached through model(masked_img_tensor),
+ *           generate_gp_training_data_imagenet.py:246) as ONE launch: the 1x1 conv3 and the 1x1 (strided) downsample
+ *           conv are K-concatenated, with the two BatchNorm scales folded into the weight rows as ratios <= 1
+ *           (s = max(|s3|,|sd|): out = relu(s*(W3*s3/s . t2 + Wd*sd/s . x) + shift3 + shiftd)), so the downsample
+ *           output never goes to HBM.  i = index of the block's conv3 ("layerN.0.conv3"); in_* = its input planes
+ *           [B][h][w][cin3], x_* = the block input planes [B][H][W][cin_ds] (H = h * stride).  mpx_forward uses this
+ *           path by default; mpx_set_fusion(h, 0) makes it run the two convs separately (bit-different, same
+ *           tolerance; for tests and ablation).  Fused planes are built once both layers have weights. */
+int mpx_conv_dual_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* x_hi,
+                         const void* x_lo, void* out_hi, void* out_lo, int B, void* stream);
+int mpx_set_fusion(mpx_engine* h, int on);
+
 /* ---- K3: maxpool 3x3 s2 p1 (nn.MaxPool2d inside the same forward), NHWC split planes ------ */
 int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,
                      void* out_lo, int B, int hin, int c, void* stream);

@@ -47,6 +47,8 @@ SIGNATURES = {
     "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_conv_dual_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_set_fusion": (_i, [_vp, _i]),
     "mpx_maxpool3x3s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mpx_global_avgpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mpx_head_softmax_gather": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -37,6 +37,17 @@ struct ConvLayer {
     bool is_fc = false;
     bool is_stem = false;
     int tile = 0;           // ConvTile<n> variant (mpx_set_conv_tile)
+    // downsample fusion (bottleneck blocks): the block's last 1x1 conv ("main") and its downsample 1x1 conv ("ds")
+    // run as ONE launch over the K-concatenation [W3 * s3/s | Wds * sds/s] (build_fused)
+    int fuse_partner = -1;  // main -> ds layer index, ds -> main layer index
+    bool fuse_main = false;
+    half_t* fw_hi = nullptr;    // main only: fused planes [cout_pad][k1 + k2]
+    half_t* fw_lo = nullptr;
+    float* fscale = nullptr;
+    float* fshift = nullptr;
+    bool fused_loaded = false;
+    std::vector<float> hw, hgamma, hbeta, hmean, hvar;   // host copies of a fusable layer's tensors (until both are in)
+    float heps = 0.f;
 };
 
 struct Op {
@@ -44,6 +55,7 @@ struct Op {
     int conv;       // layer index for OP_CONV
     int in, out, res;
     int hin, c;     // pools
+    int in2;        // fused main conv: buffer of the block input (the downsample branch's operand), else BUF_NONE
 };
 
 struct ProfRec {
@@ -71,6 +83,7 @@ struct mpx_engine {
     float* logits = nullptr;
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
+    bool fuse_ds = true;    // mpx_forward runs a block's last conv and its downsample conv as one launch (mpx_set_fusion)
     bool prof_on = false;
     std::vector<ProfRec> prof_pool;
     int prof_used = 0;
@@ -138,8 +151,8 @@ int build_topology(mpx_engine* h) {
         h->convs.push_back(L);
         return (int)h->convs.size() - 1;
     };
-    auto add_op = [&](int kind, int conv, int in, int out, int res, int hin, int c) {
-        Op o{kind, conv, in, out, res, hin, c};
+    auto add_op = [&](int kind, int conv, int in, int out, int res, int hin, int c, int in2 = BUF_NONE) {
+        Op o{kind, conv, in, out, res, hin, c, in2};
         h->ops.push_back(o);
     };
     auto pick = [&](std::initializer_list<int> busy) {
@@ -185,15 +198,19 @@ int build_topology(mpx_engine* h) {
                 const int T2 = pick({X, T1});
                 c = add_conv(p + "conv2", p + "bn2", w, w, 3, stride, 1, hcur, 1, 0);
                 add_op(OP_CONV, c, T1, T2, BUF_NONE, 0, 0);
-                int res = X;
+                int res = X, dsc = -1;
                 if (ds) {
                     const int T3 = pick({X, T1, T2});
-                    c = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
-                    add_op(OP_CONV, c, X, T3, BUF_NONE, 0, 0);
+                    dsc = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
+                    add_op(OP_CONV, dsc, X, T3, BUF_NONE, 0, 0);
                     res = T3;
                 }
                 c = add_conv(p + "conv3", p + "bn3", w, w * exp, 1, 1, 0, hout, 1, 1);
-                add_op(OP_CONV, c, T2, T1, res, 0, 0);   // T1 is dead after conv2
+                add_op(OP_CONV, c, T2, T1, res, 0, 0, ds ? X : BUF_NONE);   // T1 is dead after conv2
+                if (ds) {
+                    h->convs[c].fuse_partner = dsc; h->convs[c].fuse_main = true;
+                    h->convs[dsc].fuse_partner = c;
+                }
                 X = T1;
             }
             cin = w * exp;
@@ -235,14 +252,16 @@ struct ProfScope {
     }
 };
 
-template <class Cfg>
+template <class Cfg, bool DUAL = false>
 int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;     // weights are padded to cout_pad >= n_tiles_c * TC rows
     if (p.n_tiles_c * Cfg::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
     const int n_tiles_p = (p.M + Cfg::TP - 1) / Cfg::TP;
     const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
-    hipLaunchKernelGGL(conv_f16x3_kernel<Cfg>, dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
+    if (DUAL && (((p.k1 >> 5) - Cfg::NSX) < 0 || (((p.k1 >> 5) - Cfg::NSX) & 1)))
+        return fail(h, MPX_E_INTERNAL, "dual conv: k1/32 - ring depth must be even and >= 0");
+    hipLaunchKernelGGL((conv_f16x3_kernel<Cfg, DUAL>), dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
@@ -347,6 +366,85 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     }
 }
 
+// A block's last 1x1 conv with its downsample branch K-concatenated: out = relu(s * (W3' . t2 + Wds' . x) + shift)
+// (build_fused).  in = t2 planes [B][ho][wo][k1], x2 = block input planes [B][hin2][hin2][k2].
+int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* x2_hi,
+                      const half_t* x2_lo, half_t* y_hi, half_t* y_lo, int B, hipStream_t st) {
+    const ConvLayer& L = h->convs[i];
+    if (!L.fuse_main || !L.fused_loaded) return fail(h, MPX_E_STATE, "layer %d (%s) has no fused weights", i, L.d.name);
+    const ConvLayer& D = h->convs[L.fuse_partner];
+    ConvParams p;
+    std::memset(&p, 0, sizeof p);
+    p.w_hi = L.fw_hi; p.w_lo = L.fw_lo; p.scale = L.fscale; p.shift = L.fshift;
+    p.y_hi = y_hi; p.y_lo = y_lo;
+    p.cout = L.d.cout; p.relu = 1;
+    p.k1 = L.d.cin; p.ktot = L.d.cin + D.d.cin;
+    p.x_hi = in_hi; p.x_lo = in_lo;
+    p.hin = L.d.hin; p.win = L.d.hin; p.pix_stride = L.d.cin;
+    p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.k_per_tap = L.d.cin;
+    p.x2_hi = x2_hi; p.x2_lo = x2_lo;
+    p.hin2 = D.d.hin; p.win2 = D.d.hin; p.pix_stride2 = D.d.cin; p.stride2 = D.d.stride;
+    p.ho = L.d.hout; p.wo = L.d.hout;
+    const long long M = (long long)B * p.ho * p.wo;
+    if (M > 0x7fffffffLL || (long long)B * p.hin2 * p.win2 > 0x7fffffffLL)
+        return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
+    p.M = (int)M;
+#ifdef MPX_DIAG
+    p.stamps = h->stamps;
+#endif
+    ProfScope ps(h, st, OP_CONV, i);
+    if (L.tile == 2) return launch_conv_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
+    return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
+}
+
+// Fused planes of a (main, ds) pair from the host copies of both layers.  With s3 = g3/sqrt(v3+eps) and sd likewise,
+//   bn3(W3.t2) + bnd(Wd.x) = s * ((W3 * s3/s) . t2 + (Wd * sd/s) . x) + shift3 + shiftd,   s = max(|s3|, |sd|) per channel
+// (both ratios are <= 1 in magnitude, so a vanishing gamma on either branch is harmless).  The scaled rows are rounded
+// to fp32 once and then split into hi + lo like any other weight (22 bits); per-row power-of-two normalisation as
+// mpx_pack_conv_weights.
+int build_fused(mpx_engine* h, int main) {
+    ConvLayer& L = h->convs[main];
+    ConvLayer& D = h->convs[L.fuse_partner];
+    const int cout = L.d.cout, k1 = L.d.cin, k2 = D.d.cin, K = k1 + k2, rows = L.d.cout_pad;
+    std::vector<uint16_t> hi((size_t)rows * K, 0), lo((size_t)rows * K, 0);
+    std::vector<float> sc(rows, 0.f), sh(rows, 0.f), row(K);
+    for (int co = 0; co < cout; ++co) {
+        const double s3 = (double)L.hgamma[co] / std::sqrt((double)L.hvar[co] + (double)L.heps);
+        const double sd = (double)D.hgamma[co] / std::sqrt((double)D.hvar[co] + (double)D.heps);
+        double s = std::fmax(std::fabs(s3), std::fabs(sd));
+        if (!(s > 0.0) || !std::isfinite(s)) s = 1.0;
+        const double r3 = s3 / s, rd = sd / s;
+        float mx = 0.f;
+        for (int k = 0; k < k1; ++k) { row[k] = (float)((double)L.hw[(size_t)co * k1 + k] * r3); mx = std::fmax(mx, std::fabs(row[k])); }
+        for (int k = 0; k < k2; ++k) { row[k1 + k] = (float)((double)D.hw[(size_t)co * k2 + k] * rd); mx = std::fmax(mx, std::fabs(row[k1 + k])); }
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) {
+            int ex;
+            std::frexp(mx, &ex);
+            e = 10 - ex;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float sv = std::ldexp(row[k], e);
+            const half_t vh = (half_t)sv;
+            const half_t vl = (half_t)(sv - (float)vh);
+            hi[(size_t)co * K + k] = half_bits(vh);
+            lo[(size_t)co * K + k] = half_bits(vl);
+        }
+        sc[co] = (float)std::ldexp(s, -e);
+        sh[co] = (float)(((double)L.hbeta[co] - (double)L.hmean[co] * s3) + ((double)D.hbeta[co] - (double)D.hmean[co] * sd));
+    }
+    MPX_HIP(h, hipMemcpy(L.fw_hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.fw_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.fscale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(L.fshift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    L.fused_loaded = true;
+    for (ConvLayer* q : {&L, &D}) {          // the host copies are no longer needed
+        std::vector<float>().swap(q->hw); std::vector<float>().swap(q->hgamma); std::vector<float>().swap(q->hbeta);
+        std::vector<float>().swap(q->hmean); std::vector<float>().swap(q->hvar);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -424,8 +522,11 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     const size_t pool_plane = round_up((size_t)max_batch * h->feat * 2, 256);
     const size_t logit_bytes = round_up((size_t)max_batch * MPX_NUM_CLASSES * 4, 256);
     size_t wbytes = 0;
-    for (const ConvLayer& L : h->convs)
+    for (const ConvLayer& L : h->convs) {
         wbytes += 2 * round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
+        if (L.fuse_main)
+            wbytes += 2 * round_up((size_t)L.d.cout_pad * (L.d.cin + h->convs[L.fuse_partner].d.cin) * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
+    }
     const size_t scratch_bytes = 4096 * sizeof(float);
     const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
     e = hipMalloc((void**)&h->arena, total);
@@ -450,6 +551,13 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         L.w_lo = (half_t*)take(wb);
         L.scale = (float*)take(sb);
         L.shift = (float*)take(sb);
+        if (L.fuse_main) {
+            const size_t fb = round_up((size_t)L.d.cout_pad * (L.d.cin + h->convs[L.fuse_partner].d.cin) * 2, 256);
+            L.fw_hi = (half_t*)take(fb);
+            L.fw_lo = (half_t*)take(fb);
+            L.fscale = (float*)take(sb);
+            L.fshift = (float*)take(sb);
+        }
     }
     // the never-written borders of the input staging must be zero
     e = hipMemset(h->arena, 0, scratch_bytes + 2 * in_plane);
@@ -464,6 +572,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
@@ -519,6 +631,17 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamm
     MPX_HIP(h, hipMemcpy(L.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     L.loaded = true;
+    if (L.fuse_partner >= 0) {
+        const size_t nw = (size_t)L.d.cout * L.d.cin;       // both layers of a pair are 1x1
+        L.hw.assign(w, w + nw);
+        L.hgamma.assign(gamma, gamma + L.d.cout); L.hbeta.assign(beta, beta + L.d.cout);
+        L.hmean.assign(mean, mean + L.d.cout); L.hvar.assign(var, var + L.d.cout);
+        L.heps = eps;
+        ConvLayer& P = h->convs[L.fuse_partner];
+        const int main = L.fuse_main ? i : L.fuse_partner;
+        h->convs[main].fused_loaded = false;
+        if (!P.hw.empty()) return build_fused(h, main);
+    }
     return 0;
 }
 
@@ -652,6 +775,15 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     for (const Op& o : h->ops) {
         switch (o.kind) {
             case OP_CONV:
+                if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
+                    const ConvLayer& CL = h->convs[o.conv];
+                    const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7)) {
+                        if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
+                        rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
+                        break;
+                    }
+                }
                 if (h->convs[o.conv].is_fc)
                     rc = mpx_conv_bn_act(h, o.conv, hi(o.in), lo(o.in), nullptr, nullptr, nullptr, nullptr, logits, B, stream);
                 else
@@ -664,6 +796,23 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
         if (rc) return rc;
     }
     return 0;
+}
+
+int mpx_set_fusion(mpx_engine* h, int on) {
+    if (!h) return MPX_E_ARG;
+    h->fuse_ds = on != 0;
+    return 0;
+}
+
+int mpx_conv_dual_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* x_hi, const void* x_lo,
+                         void* out_hi, void* out_lo, int B, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (i < 0 || i >= (int)h->convs.size() || B <= 0) return fail(h, MPX_E_ARG, "conv_dual_bn_act: bad layer index or batch");
+    if (!h->convs[i].fuse_main) return fail(h, MPX_E_ARG, "conv_dual_bn_act: layer %d (%s) is not the last conv of a block with a downsample branch", i, h->convs[i].d.name);
+    if (!in_hi || !in_lo || !x_hi || !x_lo || !out_hi || !out_lo) return fail(h, MPX_E_ARG, "conv_dual_bn_act: null planes");
+    MPX_HIP(h, hipSetDevice(h->device));
+    return launch_conv_fused(h, i, (const half_t*)in_hi, (const half_t*)in_lo, (const half_t*)x_hi, (const half_t*)x_lo,
+                             (half_t*)out_hi, (half_t*)out_lo, B, as_stream(stream));
 }
 
 int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* onoff, const int32_t* pred,

@@ -280,6 +280,11 @@ class MaskedForwardEngine:
         i = layer if isinstance(layer, int) else [d.name.decode() for d in self.layers].index(layer)
         _lib.check(self._h, self._lib.mpx_set_conv_tile(self._h, int(i), int(tile)), "mpx_set_conv_tile")
 
+    def set_fusion(self, on=True):
+        """mpx_forward runs the first bottleneck's conv3 and its downsample conv as one K-concatenated launch (default);
+        off = two launches (bit-different results inside the same tolerance; for tests and ablation)."""
+        _lib.check(self._h, self._lib.mpx_set_fusion(self._h, 1 if on else 0), "mpx_set_fusion")
+
     def conv_tile(self, layer):
         i = layer if isinstance(layer, int) else [d.name.decode() for d in self.layers].index(layer)
         return int(self._lib.mpx_get_conv_tile(self._h, int(i)))

@@ -202,6 +202,62 @@ def test_conv_every_tile_variant(eng101, name, tile):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
 
 
+@pytest.mark.parametrize("tile", [-1, 2])
+@pytest.mark.parametrize("stage", [1, 2, 3, 4])
+def test_conv_with_fused_downsample(eng101, stage, tile):
+    """mpx_conv_dual_bn_act: layerN.0.conv3 + layerN.0.downsample K-concatenated in one launch (the default path of
+    mpx_forward) against relu(bn3(conv3(t2)) + bn_ds(conv_ds(x))) in fp64 on the same split inputs; ragged batch."""
+    sd = synth.make_state_dict("resnet101")
+    i = _layer_index(eng101, "layer%d.0.conv3" % stage)
+    j = _layer_index(eng101, "layer%d.0.downsample.0" % stage)
+    d3, dd = eng101.layers[i], eng101.layers[j]
+    batch = 5
+    g = torch.Generator().manual_seed(100 + stage)
+    t2 = torch.randn(batch, d3.hin, d3.hin, d3.cin, generator=g).clamp_min(0) * 1.5
+    x = torch.randn(batch, dd.hin, dd.hin, dd.cin, generator=g).clamp_min(0) * 1.5
+    dev = eng101.device
+    th, tl = split(t2.to(dev))
+    xh, xl = split(x.to(dev))
+    oh = torch.full((batch, d3.hout, d3.hout, d3.cout), float("nan"), dtype=torch.float16, device=dev)
+    ol = torch.full_like(oh, float("nan"))
+    eng101.set_conv_tile(i, tile)
+    try:
+        rc = eng101._lib.mpx_conv_dual_bn_act(eng101._h, i, _p(th), _p(tl), _p(xh), _p(xl), _p(oh), _p(ol), batch, eng101._stream())
+        _lib.check(eng101._h, rc, "mpx_conv_dual_bn_act")
+        torch.cuda.synchronize()
+    finally:
+        eng101.set_conv_tile(i, -1)
+
+    def branch(d, inp):
+        name, bn = d.name.decode(), d.bn_name.decode()
+        y = F.conv2d(inp.double().permute(0, 3, 1, 2), sd[name + ".weight"].double(), None, d.stride, d.pad)
+        sc = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+        return (y - sd[bn + ".running_mean"].double().view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + sd[bn + ".bias"].double().view(1, -1, 1, 1)
+
+    want = F.relu(branch(d3, merge(th, tl).cpu()) + branch(dd, merge(xh, xl).cpu())).permute(0, 2, 3, 1)
+    got = merge(oh, ol).cpu().double()
+    assert not torch.isnan(got).any()
+    err = (got - want).abs().max().item()
+    assert err <= 4e-6 * max(want.abs().max().item(), 1.0), "stage %d: %.3e" % (stage, err)
+    assert eng101._lib.mpx_conv_dual_bn_act(eng101._h, i + 1, _p(th), _p(tl), _p(xh), _p(xl), _p(oh), _p(ol), batch, None) == -1
+
+
+def test_forward_fused_vs_unfused_downsample(eng101):
+    """The same masks with the downsample fusion on (default) and off: two different summation orders of the same
+    arithmetic, so the scores agree to rounding, not bit for bit."""
+    img = synth.make_images(1, seed=8, kind="noise")[0]
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(24, 196, seed=5)
+    _o, s_fused, p_fused = eng101.score_masks(img, seg, onoff, 17)
+    eng101.set_fusion(False)
+    try:
+        _o, s_plain, p_plain = eng101.score_masks(img, seg, onoff, 17)
+    finally:
+        eng101.set_fusion(True)
+    assert np.abs(s_fused - s_plain).max() <= 2e-6 and (p_fused == p_plain).all()
+    assert not (s_fused == s_plain).all()          # they really are two code paths
+
+
 TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_layers_cifar_resnet56.npz")
 
 
