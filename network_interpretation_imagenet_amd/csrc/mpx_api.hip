@@ -3,6 +3,7 @@
 #include "../../include/mpx.h"
 #include "mpx_kernels.h"
 #include "mpx_conv3p.h"
+#include "mpx_convp.h"
 
 #include <algorithm>
 #include <cmath>
@@ -68,6 +69,7 @@ struct ProfRec {
 
 struct mpx_engine {
     int arch = 0, max_batch = 0, device = 0;
+    int num_cus = 256;
     bool bottleneck = false;
     int feat = 0;
     std::vector<ConvLayer> convs;
@@ -266,6 +268,26 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     return 0;
 }
 
+// Persistent kernels (mpx_convp.h, tile ids 8 = the 128x128 4-wave tile, 9 = its 8-wave form): a fixed grid of
+// MINB-per-CU workgroups walks all tiles.
+template <class Cfg, bool DUAL = false>
+int launch_convp_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;
+    if (p.n_tiles_c * Cfg::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const int n_tiles_p = (p.M + Cfg::TP - 1) / Cfg::TP;
+    const long long n_tiles = (long long)n_tiles_p * p.n_tiles_c;
+    if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    if (DUAL && (((p.k1 >> 5) - Cfg::NSX) < 0 || (((p.k1 >> 5) - Cfg::NSX) & 1)))
+        return fail(h, MPX_E_INTERNAL, "dual conv: k1/32 - ring depth must be even and >= 0");
+    p.n_tiles = (int)n_tiles;
+    const int wg_per_cu = (160 * 1024) / Cfg::RING < Cfg::MINB * 256 / Cfg::NT ? (160 * 1024) / Cfg::RING : Cfg::MINB * 256 / Cfg::NT;
+    const long long resident = (long long)h->num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);     // a multiple of 8 (256 CUs)
+    const unsigned grid = (unsigned)(n_tiles < resident ? n_tiles : resident);
+    hipLaunchKernelGGL((convp_f16x3_kernel<Cfg, DUAL>), dim3(grid), dim3(Cfg::NT), Cfg::RING, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Rows of the largest input patch any TP-pixel tile of an HxH map needs (mpx_conv3p.h), rounded up to 16.
 int patch_rows_needed(int H, int TP) {
     const int W = H, PW = W + 2, PIMG = (H + 2) * PW, howo = H * W;
@@ -356,6 +378,8 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
     switch (L.tile) {
+        case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
+        case 9: return launch_convp_tile<ConvTile7>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
@@ -394,6 +418,8 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
 #endif
     ProfScope ps(h, st, OP_CONV, i);
     if (L.tile == 2) return launch_conv_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
+    if (L.tile == 8) return launch_convp_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
+    if (L.tile == 9) return launch_convp_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
     return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
 }
 
@@ -515,6 +541,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (rc) { delete h; return rc; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return (int)e; }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
 
     // one arena: scratch | input planes | activation planes | pooled | logits | weights
     const size_t in_plane = round_up((size_t)max_batch * MPX_IMG_PAD * MPX_IMG_PAD * 4 * 2 + 256, 256);
@@ -576,6 +606,14 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::RING);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::RING);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
@@ -650,7 +688,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 7) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 9) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile >= 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernels (8, 9) run conv layers with cout >= 128 (%s is not one)", L.d.name);
     if (tile == 6 && !patch_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;
@@ -778,7 +818,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7)) {
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 9)) {
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

@@ -195,14 +195,27 @@ def test_conv_layers_resnet101(eng101, name):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 8, 9])
 @pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv3", "layer2.0.conv2", "layer3.5.conv2", "layer4.2.conv3"])
 def test_conv_every_tile_variant(eng101, name, tile):
     """Each kernel variant (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""
+    if tile >= 8 and name == "layer1.0.conv1":
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, _layer_index(eng101, name), tile) == -1     # persistent tiles: cout >= 128
+        return
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [-1, 2])
+@pytest.mark.parametrize("tile", [8, 9])
+@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 161), ("layer3.5.conv1", 201), ("layer2.1.conv3", 25), ("layer1.1.conv3", 25),
+                                        ("layer4.1.conv1", 401), ("layer3.0.conv2", 201)])
+def test_conv_persistent_kernel_many_tiles(eng101, name, tile, batch):
+    """The persistent kernels (csrc/mpx_convp.h) with MORE tiles than the 512 resident workgroups (600 .. 2000 tiles,
+    ragged last tile), so that workgroups walk several tiles: next-tile prologue under the epilogue, ring hand-over,
+    counted waits across tiles.  (mpx_conv_bn_act takes caller planes, so the batch is not bound by the engine's.)"""
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=tile)
+
+
+@pytest.mark.parametrize("tile", [-1, 2, 7, 8, 9])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):
     """mpx_conv_dual_bn_act: layerN.0.conv3 + layerN.0.downsample K-concatenated in one launch (the default path of
