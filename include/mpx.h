@@ -39,7 +39,15 @@ enum {
 };
 
 /* arch_id = the torchvision ResNet depth the reference selects with `-a` / `--arch`
- * (generate_gp_training_data_imagenet.py:45,579): 18, 34, 50, 101 or 152. */
+ * (generate_gp_training_data_imagenet.py:45,579): 18, 34, 50, 101 or 152 -- or one of the reference's two small networks
+ * (SURVEY.md 8 f4), whose trained checkpoints ship with it:
+ *   MPX_ARCH_MNIST_NET            Classification_Net, 28x28x1 -> 10 (generate_gp_training_data_mnist.py:86-105)
+ *   MPX_ARCH_CIFAR_RESNET + depth ResNetCifar(depth = 6n+2), 32x32x3 -> 10 (models/resnet.py:77-146; the checkpoint is depth 56)
+ * Small-network engines stage inputs with mpx_mask_apply_minmax (their scorers' mask convention) instead of
+ * mpx_mask_apply_normalize, keep activations as NHWC planes with channels padded to a multiple of 32, and score 10 classes
+ * (logit rows are 16 floats apart: mpx_geometry). */
+#define MPX_ARCH_MNIST_NET 1
+#define MPX_ARCH_CIFAR_RESNET 2000
 typedef struct mpx_engine mpx_engine;
 
 typedef struct mpx_conv_desc {
@@ -61,6 +69,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out);
 int mpx_destroy(mpx_engine* h);
 const char* mpx_last_error(const mpx_engine* h);   /* "" if none; valid until next call */
 int mpx_max_batch(const mpx_engine* h);
+/* 224/3/1000/1000 for the ImageNet ResNets, 28/1/10/16 and 32/3/10/16 for the small networks; any pointer may be NULL */
+int mpx_geometry(const mpx_engine* h, int* image_size, int* in_channels, int* num_classes, int* logit_pitch);
 size_t mpx_workspace_bytes(const mpx_engine* h);
 
 /* ---- topology / weights ------------------------------------------------------------------
@@ -69,11 +79,12 @@ int mpx_num_convs(const mpx_engine* h);
 int mpx_conv_info(const mpx_engine* h, int i, mpx_conv_desc* out);
 
 /* replaces: the state_dict tensors torchvision loads (same line as above).  HOST pointers, f32:
- * w = conv weight OIHW [cout][cin][k][k]; gamma/beta/mean/var = BatchNorm weight/bias/
- * running_mean/running_var [cout]; eps = 1e-5 for torchvision.  For the last entry ("fc"):
- * w = fc.weight [1000][C], beta = fc.bias, gamma/mean/var = NULL.  Packs on the host
- * (mpx_pack_conv_weights) and uploads synchronously. */
-int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamma,
+ * w = conv weight OIHW [cout][cin][k][k]; conv_bias = the conv's own bias [cout] or NULL (torchvision's ResNet convs have
+ * none; the MNIST net's nn.Conv2d do, generate_gp_training_data_mnist.py:72-77); gamma/beta/mean/var = BatchNorm
+ * weight/bias/running_mean/running_var [cout]; eps = 1e-5.  For a layer without BatchNorm (bn_name "": "fc", the MNIST
+ * net's "conv6"): beta = its bias, gamma/mean/var/conv_bias = NULL.  Packs on the host (mpx_pack_conv_weights) and
+ * uploads synchronously. */
+int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv_bias, const float* gamma,
                          const float* beta, const float* mean, const float* var, float eps);
 int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has weights */
 
@@ -91,9 +102,10 @@ int mpx_get_conv_tile(const mpx_engine* h, int i);
  * Produces the fp16 planes w_hi/w_lo [cout_pad][k_packed] (k order = (ky,kx,ci), ci fastest;
  * for the 7x7 stem k = ky*32 + px*4 + c over the NHWC4 padded input), each output channel
  * multiplied by 2^e so that max|w| lies in [512,1024), and the fp32 epilogue
- * scale = gamma/sqrt(var+eps) * 2^-e, shift = beta - mean*gamma/sqrt(var+eps).
+ * scale = gamma/sqrt(var+eps) * 2^-e, shift = beta + (conv_bias - mean)*gamma/sqrt(var+eps).  k_packed = k*k*cin_pad
+ * with cin_pad >= cin the channels per pixel of the input planes (padding channels get zero weights).
  * All outputs are HOST buffers sized from mpx_conv_desc (uint16_t = raw fp16 bits). */
-int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma,
+int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* conv_bias, const float* gamma,
                           const float* beta, const float* mean, const float* var, float eps,
                           uint16_t* w_hi, uint16_t* w_lo, float* scale, float* shift);
 /* ---- K0: mask-apply + normalise ----------------------------------------------------------
@@ -112,6 +124,23 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
                              const int32_t* seg, const uint8_t* onoff, int M, int S,
                              const float mean[3], const float std[3], int slot0,
                              float* out_f32_nchw, void* stream);
+
+/* ---- K0 of the small networks: the CIFAR / MNIST scorers' mask convention ---------------------------
+ * replaces: the in-place min-max rescale of the picture to [0,255] (generate_gp_training_data_cifar.py:274-279,
+ *           generate_gp_training_data_mnist.py:167-171), `mask.fill(255); mask[segments == segVal] = 0` for the SELECTED
+ *           superpixels (:310-313 / :213-217), `masked_img = org_img * mask`, the second in-place min-max rescale and
+ *           normalize_image = * f32(1/255) (:315-321 / :220-242, utils.py:92-94), and the per-mask H2D copy.
+ * img_f32_chw: DEV f32[C][H][W] as the loader yields it; seg: DEV i32[H][W] ranks in [0,S), S <= 4096;
+ * removed: DEV u8[M][S], removed[m][s] != 0 switches superpixel s OFF in mask m.  Writes input slots [slot0, slot0+M) and,
+ * if out_f32_nchw (DEV f32[M][C][H][W]) is non-NULL, the network input in the reference's layout (bit-exact against the
+ * NumPy arithmetic; a mask that removes every pixel gives NaN, as 0/0 does upstream). */
+int mpx_mask_apply_minmax(mpx_engine* h, const float* img_f32_chw, const int32_t* seg, const uint8_t* removed,
+                          int M, int S, int slot0, float* out_f32_nchw, void* stream);
+
+/* ---- DownsampleB (models/resnet.py:64-74): AvgPool2d(2) on the identity + zero channels; planes
+ * [B][hin][hin][cin_p] -> [B][hin/2][hin/2][cout_p] (channel counts as stored: multiples of 8, cout_p >= cin_p). */
+int mpx_avgpool2_pad(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B,
+                     int hin, int cin_p, int cout_p, void* stream);
 
 /* ---- K1/K2: conv + BN (+ residual) (+ ReLU), one layer ------------------------------------
  * replaces: one nn.Conv2d -> nn.BatchNorm2d (-> `out += identity`) (-> nn.ReLU) group inside

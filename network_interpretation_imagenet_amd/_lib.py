@@ -40,11 +40,14 @@ SIGNATURES = {
     "mpx_workspace_bytes": (C.c_size_t, [_vp]),
     "mpx_num_convs": (_i, [_vp]),
     "mpx_conv_info": (_i, [_vp, _i, C.POINTER(ConvDesc)]),
-    "mpx_set_conv_weights": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f]),
+    "mpx_set_conv_weights": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f]),
+    "mpx_geometry": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mpx_mask_apply_minmax": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mpx_avgpool2_pad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mpx_weights_complete": (_i, [_vp]),
     "mpx_set_conv_tile": (_i, [_vp, _i, _i]),
     "mpx_get_conv_tile": (_i, [_vp, _i]),
-    "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_conv_dual_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

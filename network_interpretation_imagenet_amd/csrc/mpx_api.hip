@@ -23,9 +23,10 @@ namespace {
 constexpr int kActBufs = 4;
 constexpr int kStemK = 7;
 constexpr int kProfilePairs = 4096;
-constexpr size_t kActElemsPerImage = 112 * 112 * 64;   // largest activation (stem output, = 56*56*256)
+constexpr size_t kActElemsPerImage = 112 * 112 * 64;   // ImageNet: largest activation (stem output, = 56*56*256)
+constexpr int kSmallCPad = 32;                         // small nets: channels are stored padded to a multiple of 32
 
-enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3 };
+enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3, OP_AVGPAD = 4 };
 enum Buf { BUF_INPUT = -1, BUF_POOL = -2, BUF_NONE = -3 };
 
 struct ConvLayer {
@@ -37,6 +38,9 @@ struct ConvLayer {
     bool loaded = false;
     bool is_fc = false;
     bool is_stem = false;
+    bool has_bias = false;  // the reference module is nn.Conv2d(bias=True) (small nets): state_dict has <name>.bias
+    int cin_pad = 0;        // channels per pixel of the input planes (= cin except for the small nets, which pad to 32)
+    int cout_store = 0;     // channels per pixel of the output planes (row pitch and store bound)
     int tile = 0;           // ConvTile<n> variant (mpx_set_conv_tile)
     // downsample fusion (bottleneck blocks): the block's last 1x1 conv ("main") and its downsample 1x1 conv ("ds")
     // run as ONE launch over the K-concatenation [W3 * s3/s | Wds * sds/s] (build_fused)
@@ -70,6 +74,12 @@ struct ProfRec {
 struct mpx_engine {
     int arch = 0, max_batch = 0, device = 0;
     int num_cus = 256;
+    // geometry of the network family: ImageNet ResNets (224x224x3, padded NHWC4 staging for the 7x7 stem, 1000 classes) or
+    // the reference's two small networks (28x28x1 / 32x32x3, staging [B][H][W][32] read by a generic 3x3 conv, 10 classes)
+    int img = MPX_IMG, in_ch = 3, ncls = MPX_NUM_CLASSES, logit_pitch = MPX_NUM_CLASSES;
+    bool small = false;
+    size_t act_elems_per_image = 0;
+    float* k0_scratch = nullptr;    // small nets: f32[2 + 4096 + max_batch]: image min, max-min, per-superpixel max, per-mask max
     bool bottleneck = false;
     int feat = 0;
     std::vector<ConvLayer> convs;
@@ -126,7 +136,12 @@ void set_name(char* dst, const std::string& s) {
 int default_tile(const mpx_conv_desc& d);
 
 // torchvision ResNet topology (models/resnet.py, un-vendored): conv list and op list.
+int build_topology_small(mpx_engine* h);
+
 int build_topology(mpx_engine* h) {
+    if (h->arch == MPX_ARCH_MNIST_NET || (h->arch > MPX_ARCH_CIFAR_RESNET && h->arch < MPX_ARCH_CIFAR_RESNET + 1000))
+        return build_topology_small(h);
+    h->act_elems_per_image = kActElemsPerImage;
     int depths[4];
     switch (h->arch) {
         case 18: depths[0] = 2; depths[1] = 2; depths[2] = 2; depths[3] = 2; h->bottleneck = false; break;
@@ -147,6 +162,8 @@ int build_topology(mpx_engine* h) {
         L.d.hin = hin; L.d.hout = (hin + 2 * pad - k) / stride + 1;
         L.d.relu = relu; L.d.residual = residual;
         L.is_stem = (cin == 3);
+        L.cin_pad = cin;
+        L.cout_store = cout;
         L.d.k_packed = L.is_stem ? kStemK * 32 : k * k * cin;
         L.d.cout_pad = (int)round_up(cout, 128);
         L.tile = default_tile(L.d);
@@ -225,6 +242,119 @@ int build_topology(mpx_engine* h) {
     h->convs[c].is_fc = true;
     add_op(OP_CONV, c, BUF_POOL, BUF_NONE, BUF_NONE, 0, 0);
     add_op(OP_HEAD, -1, BUF_NONE, BUF_NONE, BUF_NONE, 0, 0);
+    return 0;
+}
+
+// The reference's small networks.  Channels are stored padded to 32 (zero weights / zero scale and
+// shift on the padding, so padded channels stay exactly 0 through ReLU and residual adds).
+//   MPX_ARCH_MNIST_NET: Classification_Net, generate_gp_training_data_mnist.py:86-105
+//       conv1..5 = Conv2d(3x3, pad 1, BIAS) + BN + ReLU (strides 1,1,2,1,2; 1->32->32->64->64->128), conv6 = Conv2d(128,128,3,pad 1)
+//       with bias and nothing else, mean over HxW, fc1 128->10.
+//   MPX_ARCH_CIFAR_RESNET + depth: ResNetCifar(depth = 6n+2), models/resnet.py:77-146: conv3x3(3->16)+BN+ReLU, three stages
+//       of n BasicBlocks (16, 32, 64 planes; the first block of stages 2 and 3 has stride 2 and DownsampleB = AvgPool2d(2) +
+//       zero channels on the identity, :64-74), AvgPool2d(8), fc 64->10.
+int build_topology_small(mpx_engine* h) {
+    h->small = true;
+    h->ncls = 10;
+    h->logit_pitch = 16;
+    auto add_conv = [&](const std::string& name, const std::string& bn, int cin, int cout, int k, int stride, int pad,
+                        int hin, int relu, int residual, bool bias, bool fc) {
+        ConvLayer L;
+        std::memset(&L.d, 0, sizeof L.d);
+        set_name(L.d.name, name);
+        set_name(L.d.bn_name, bn);
+        L.d.cin = cin; L.d.cout = cout; L.d.ksize = k; L.d.stride = stride; L.d.pad = pad;
+        L.d.hin = hin; L.d.hout = (hin + 2 * pad - k) / stride + 1;
+        L.d.relu = relu; L.d.residual = residual;
+        L.has_bias = bias;
+        L.is_fc = fc;
+        L.cin_pad = (int)round_up(cin, kSmallCPad);
+        L.cout_store = fc ? h->logit_pitch : (int)round_up(cout, kSmallCPad);
+        L.d.k_packed = k * k * L.cin_pad;
+        L.d.cout_pad = (int)round_up(cout, 128);
+        L.tile = default_tile(L.d);
+        h->convs.push_back(L);
+        return (int)h->convs.size() - 1;
+    };
+    auto add_op = [&](int kind, int conv, int in, int out, int res, int hin, int c) {
+        Op o{kind, conv, in, out, res, hin, c, BUF_NONE};
+        h->ops.push_back(o);
+    };
+    int feat = 0, hlast = 0, X = 0;
+    size_t act = 0;
+    auto track = [&](int hout, int c) { act = std::max(act, (size_t)hout * hout * round_up(c, kSmallCPad)); };
+    if (h->arch == MPX_ARCH_MNIST_NET) {
+        h->img = 28; h->in_ch = 1;
+        const int cfg[5][3] = {{1, 32, 1}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}, {64, 128, 2}};
+        int hcur = 28, in = BUF_INPUT;
+        for (int i = 0; i < 5; ++i) {
+            const std::string n = "conv" + std::to_string(i + 1);
+            const int c = add_conv(n + ".0", n + ".1", cfg[i][0], cfg[i][1], 3, cfg[i][2], 1, hcur, 1, 0, true, false);
+            const int out = (in == 0) ? 1 : 0;
+            add_op(OP_CONV, c, in, out, BUF_NONE, 0, 0);
+            in = out;
+            hcur = h->convs[c].d.hout;
+            track(hcur, cfg[i][1]);
+        }
+        const int c6 = add_conv("conv6", "", 128, 128, 3, 1, 1, hcur, 0, 0, true, false);     // bias only: packed like fc (gamma = NULL)
+        X = (in == 0) ? 1 : 0;
+        add_op(OP_CONV, c6, in, X, BUF_NONE, 0, 0);
+        feat = 128; hlast = hcur;
+        h->feat = feat;
+        add_op(OP_AVGPOOL, -1, X, BUF_POOL, BUF_NONE, hlast, feat);
+        const int cf = add_conv("fc1", "", feat, 10, 1, 1, 0, 1, 0, 0, true, true);
+        add_op(OP_CONV, cf, BUF_POOL, BUF_NONE, BUF_NONE, 0, 0);
+    } else {
+        const int depth = h->arch - MPX_ARCH_CIFAR_RESNET;
+        if (depth < 8 || (depth - 2) % 6 != 0) return MPX_E_ARG;
+        const int n = (depth - 2) / 6;
+        h->img = 32; h->in_ch = 3;
+        int c = add_conv("conv1", "bn1", 3, 16, 3, 1, 1, 32, 1, 0, false, false);
+        add_op(OP_CONV, c, BUF_INPUT, 0, BUF_NONE, 0, 0);
+        track(32, 16);
+        X = 0;
+        int inplanes = 16, hcur = 32;
+        const int planes_of[3] = {16, 32, 64};
+        for (int sidx = 0; sidx < 3; ++sidx) {
+            const int planes = planes_of[sidx];
+            for (int b = 0; b < n; ++b) {
+                const int stride = (sidx > 0 && b == 0) ? 2 : 1;
+                const std::string p = "layer" + std::to_string(sidx + 1) + "." + std::to_string(b) + ".";
+                int busy[3] = {X, -1, -1};
+                auto pick = [&]() {
+                    for (int q = 0; q < kActBufs; ++q)
+                        if (q != busy[0] && q != busy[1] && q != busy[2]) return q;
+                    return -100;
+                };
+                const int T1 = pick();
+                busy[1] = T1;
+                c = add_conv(p + "conv1", p + "bn1", inplanes, planes, 3, stride, 1, hcur, 1, 0, false, false);
+                add_op(OP_CONV, c, X, T1, BUF_NONE, 0, 0);
+                const int hout = h->convs[c].d.hout;
+                int res = X;
+                if (stride != 1 || inplanes != planes) {            // DownsampleB on the identity
+                    const int T2 = pick();
+                    busy[2] = T2;
+                    add_op(OP_AVGPAD, -1, X, T2, BUF_NONE, hcur, (int)round_up(inplanes, kSmallCPad) * 65536 + (int)round_up(planes, kSmallCPad));
+                    res = T2;
+                }
+                const int O = pick();
+                c = add_conv(p + "conv2", p + "bn2", planes, planes, 3, 1, 1, hout, 1, 1, false, false);
+                add_op(OP_CONV, c, T1, O, res, 0, 0);
+                X = O;
+                inplanes = planes;
+                hcur = hout;
+                track(hcur, planes);
+            }
+        }
+        feat = 64; hlast = hcur;
+        h->feat = feat;
+        add_op(OP_AVGPOOL, -1, X, BUF_POOL, BUF_NONE, hlast, feat);
+        const int cf = add_conv("fc", "", feat, 10, 1, 1, 0, 1, 0, 0, true, true);
+        add_op(OP_CONV, cf, BUF_POOL, BUF_NONE, BUF_NONE, 0, 0);
+    }
+    add_op(OP_HEAD, -1, BUF_NONE, BUF_NONE, BUF_NONE, 0, 0);
+    h->act_elems_per_image = act;
     return 0;
 }
 
@@ -351,7 +481,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     std::memset(&p, 0, sizeof p);
     p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.scale = L.scale; p.shift = L.shift;
     p.r_hi = r_hi; p.r_lo = r_lo; p.y_hi = y_hi; p.y_lo = y_lo; p.y_f32 = y_f32;
-    p.cout = L.d.cout;
+    p.cout = L.cout_store;
     p.relu = L.d.relu;
     p.ktot = L.d.k_packed;
     if (L.is_stem) {
@@ -361,8 +491,8 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         p.kh = kStemK; p.kw = 1; p.stride = 2; p.pad = 0; p.k_per_tap = 32;
     } else {
         p.x_hi = in_hi; p.x_lo = in_lo;
-        p.hin = L.d.hin; p.win = L.d.hin; p.pix_stride = L.d.cin;
-        p.kh = L.d.ksize; p.kw = L.d.ksize; p.stride = L.d.stride; p.pad = L.d.pad; p.k_per_tap = L.d.cin;
+        p.hin = L.d.hin; p.win = L.d.hin; p.pix_stride = L.cin_pad;
+        p.kh = L.d.ksize; p.kw = L.d.ksize; p.stride = L.d.stride; p.pad = L.d.pad; p.k_per_tap = L.cin_pad;
     }
     p.ho = L.d.hout; p.wo = L.d.hout;
     const long long M = (long long)B * p.ho * p.wo;
@@ -476,13 +606,16 @@ int build_fused(mpx_engine* h, int main) {
 // =============================================================================================
 extern "C" {
 
-int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* gamma, const float* beta,
-                          const float* mean, const float* var, float eps, uint16_t* w_hi, uint16_t* w_lo,
-                          float* scale, float* shift) {
+int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* conv_bias, const float* gamma,
+                          const float* beta, const float* mean, const float* var, float eps, uint16_t* w_hi,
+                          uint16_t* w_lo, float* scale, float* shift) {
     if (!d || !w || !w_hi || !w_lo || !scale || !shift) return MPX_E_ARG;
     const int cin = d->cin, cout = d->cout, k = d->ksize, K = d->k_packed;
-    const bool stem = (cin == 3);
-    if (stem ? (k != kStemK || K != kStemK * 32) : (K != k * k * cin || K % 32 != 0)) return MPX_E_ARG;
+    const bool stem = (cin == 3 && k == kStemK);
+    if (k <= 0 || cin <= 0 || cout <= 0 || cout > d->cout_pad) return MPX_E_ARG;
+    // K = k*k*cin_pad: the input planes may carry more channels per pixel than the layer reads (small nets pad to 32)
+    const int cin_pad = stem ? 0 : K / (k * k);
+    if (stem ? (K != kStemK * 32) : (K != k * k * cin_pad || cin_pad < cin || K % 32 != 0)) return MPX_E_ARG;
     std::memset(w_hi, 0, (size_t)d->cout_pad * K * 2);
     std::memset(w_lo, 0, (size_t)d->cout_pad * K * 2);
     for (int co = 0; co < d->cout_pad; ++co) {
@@ -516,14 +649,16 @@ int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* g
             for (int ky = 0; ky < k; ++ky)
                 for (int kx = 0; kx < k; ++kx)
                     for (int ci = 0; ci < cin; ++ci)
-                        put((ky * k + kx) * cin + ci, wc[((size_t)ci * k + ky) * k + kx]);
+                        put((ky * k + kx) * cin_pad + ci, wc[((size_t)ci * k + ky) * k + kx]);
         }
+        // y = bn(conv(x) + conv_bias) = s * acc + (beta + (conv_bias - mean) * s); without BatchNorm: y = acc + beta (+ conv_bias)
         double s = 1.0, t = 0.0;
+        const double cb = conv_bias ? (double)conv_bias[co] : 0.0;
         if (gamma) {
             s = (double)gamma[co] / std::sqrt((double)var[co] + (double)eps);
-            t = (double)beta[co] - (double)mean[co] * s;
-        } else if (beta) {
-            t = beta[co];
+            t = (double)beta[co] + (cb - (double)mean[co]) * s;
+        } else {
+            t = (beta ? (double)beta[co] : 0.0) + cb;
         }
         scale[co] = (float)std::ldexp(s, -e);
         shift[co] = (float)t;
@@ -547,10 +682,12 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     }
 
     // one arena: scratch | input planes | activation planes | pooled | logits | weights
-    const size_t in_plane = round_up((size_t)max_batch * MPX_IMG_PAD * MPX_IMG_PAD * 4 * 2 + 256, 256);
-    const size_t act_plane = round_up((size_t)max_batch * kActElemsPerImage * 2, 256);
-    const size_t pool_plane = round_up((size_t)max_batch * h->feat * 2, 256);
-    const size_t logit_bytes = round_up((size_t)max_batch * MPX_NUM_CLASSES * 4, 256);
+    const size_t in_elems = h->small ? (size_t)h->img * h->img * kSmallCPad : (size_t)MPX_IMG_PAD * MPX_IMG_PAD * 4;
+    const size_t in_plane = round_up((size_t)max_batch * in_elems * 2 + 256, 256);
+    const size_t act_plane = round_up((size_t)max_batch * h->act_elems_per_image * 2, 256);
+    const size_t pool_plane = round_up((size_t)max_batch * round_up(h->feat, kSmallCPad) * 2, 256);
+    const size_t logit_bytes = round_up((size_t)max_batch * h->logit_pitch * 4, 256);
+    const size_t k0_bytes = h->small ? round_up((size_t)(2 + 4096 + max_batch) * sizeof(float), 256) : 0;
     size_t wbytes = 0;
     for (const ConvLayer& L : h->convs) {
         wbytes += 2 * round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
@@ -558,7 +695,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
             wbytes += 2 * round_up((size_t)L.d.cout_pad * (L.d.cin + h->convs[L.fuse_partner].d.cin) * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
     }
     const size_t scratch_bytes = 4096 * sizeof(float);
-    const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + wbytes;
+    const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
     h->arena_bytes = total;
@@ -574,6 +711,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     h->pool_hi = (half_t*)take(pool_plane);
     h->pool_lo = (half_t*)take(pool_plane);
     h->logits = (float*)take(logit_bytes);
+    if (k0_bytes) h->k0_scratch = (float*)take(k0_bytes);
     for (ConvLayer& L : h->convs) {
         const size_t wb = round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256);
         const size_t sb = round_up((size_t)L.d.cout_pad * 4, 256);
@@ -589,8 +727,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
             L.fshift = (float*)take(sb);
         }
     }
-    // the never-written borders of the input staging must be zero
+    // the never-written borders (ImageNet) / padding channels (small nets) of the input staging must be zero, and so must
+    // the pooled planes' padding channels
     e = hipMemset(h->arena, 0, scratch_bytes + 2 * in_plane);
+    if (e == hipSuccess) e = hipMemset(h->pool_hi, 0, 2 * pool_plane);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
@@ -652,16 +792,19 @@ int mpx_conv_info(const mpx_engine* h, int i, mpx_conv_desc* out) {
     return 0;
 }
 
-int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* gamma, const float* beta,
+int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv_bias, const float* gamma, const float* beta,
                          const float* mean, const float* var, float eps) {
     if (!h) return MPX_E_ARG;
     if (i < 0 || i >= (int)h->convs.size() || !w) return fail(h, MPX_E_ARG, "set_conv_weights: bad layer index or null weight");
     ConvLayer& L = h->convs[i];
-    if (!L.is_fc && (!gamma || !beta || !mean || !var)) return fail(h, MPX_E_ARG, "set_conv_weights: BatchNorm tensors missing for %s", L.d.name);
+    const bool has_bn = L.d.bn_name[0] != 0;
+    if (has_bn && (!gamma || !beta || !mean || !var)) return fail(h, MPX_E_ARG, "set_conv_weights: BatchNorm tensors missing for %s", L.d.name);
+    if (!has_bn) gamma = nullptr;
+    if (L.has_bias && has_bn && !conv_bias) return fail(h, MPX_E_ARG, "set_conv_weights: %s is a conv with bias; conv_bias missing", L.d.name);
     const size_t n = (size_t)L.d.cout_pad * L.d.k_packed;
     std::vector<uint16_t> hi(n), lo(n);
     std::vector<float> sc(L.d.cout_pad), sh(L.d.cout_pad);
-    int rc = mpx_pack_conv_weights(&L.d, w, L.is_fc ? nullptr : gamma, beta, mean, var, eps, hi.data(), lo.data(), sc.data(), sh.data());
+    int rc = mpx_pack_conv_weights(&L.d, w, conv_bias, gamma, beta, mean, var, eps, hi.data(), lo.data(), sc.data(), sh.data());
     if (rc) return fail(h, rc, "pack failed for %s", L.d.name);
     MPX_HIP(h, hipSetDevice(h->device));
     MPX_HIP(h, hipMemcpy(L.w_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
@@ -713,6 +856,7 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
                              const uint8_t* onoff, int M, int S, const float mean[3], const float std[3], int slot0,
                              float* out_f32_nchw, void* stream) {
     if (!h) return MPX_E_ARG;
+    if (h->small) return fail(h, MPX_E_STATE, "mask_apply_normalize: this engine runs one of the small networks; use mpx_mask_apply_minmax");
     if ((img_u8_hwc == nullptr) == (img_f32_chw == nullptr))
         return fail(h, MPX_E_ARG, "mask_apply_normalize: exactly one of img_u8_hwc / img_f32_chw must be given");
     if (!seg || !onoff || M <= 0 || S <= 0) return fail(h, MPX_E_ARG, "mask_apply_normalize: null input or empty M/S");
@@ -739,6 +883,57 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
     return 0;
 }
 
+int mpx_mask_apply_minmax(mpx_engine* h, const float* img_f32_chw, const int32_t* seg, const uint8_t* removed, int M, int S,
+                          int slot0, float* out_f32_nchw, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!h->small) return fail(h, MPX_E_STATE, "mask_apply_minmax: only the small networks (MNIST net, CIFAR ResNet) use this mask convention");
+    if (!img_f32_chw || !seg || !removed || M <= 0 || S <= 0 || S > 4096) return fail(h, MPX_E_ARG, "mask_apply_minmax: null input, empty M/S or S > 4096");
+    if (slot0 < 0 || slot0 + M > h->max_batch) return fail(h, MPX_E_STATE, "mask_apply_minmax: slots [%d,%d) exceed max_batch %d", slot0, slot0 + M, h->max_batch);
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 1, -1);
+    const int hw = h->img * h->img;
+    float* stats = h->k0_scratch;
+    float* mask_max = h->k0_scratch + 2 + 4096;
+    hipLaunchKernelGGL(smallnet_image_stats_kernel, dim3(1), dim3(256), 0, st, img_f32_chw, seg, h->in_ch, hw, S, stats);
+    MPX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(smallnet_mask_max_kernel, dim3((M + 255) / 256), dim3(256), 0, st, removed, M, S, (const float*)stats, mask_max);
+    MPX_HIP(h, hipGetLastError());
+    SmallMaskParams p;
+    std::memset(&p, 0, sizeof p);
+    p.img = img_f32_chw; p.seg = seg; p.removed = removed; p.stats = stats; p.mask_max = mask_max;
+    p.out_hi = h->in_hi; p.out_lo = h->in_lo; p.out_f32 = out_f32_nchw;
+    p.C = h->in_ch; p.hw = hw; p.M = M; p.S = S; p.slot0 = slot0;
+    hipLaunchKernelGGL(smallnet_mask_apply_kernel, dim3((hw + 255) / 256, M), dim3(256), 0, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_avgpool2_pad(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi, void* out_lo, int B, int hin,
+                     int cin_p, int cout_p, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hin <= 0 || (hin & 1) || cin_p <= 0 || (cin_p & 7) || cout_p < cin_p || (cout_p & 7))
+        return fail(h, MPX_E_ARG, "avgpool2_pad: bad arguments (hin even, channel counts multiples of 8, cout_p >= cin_p)");
+    MPX_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 2, -1);
+    const size_t total = (size_t)B * (hin / 2) * (hin / 2) * (cout_p / 8);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(avgpool2_pad_kernel, dim3(grid), dim3(256), 0, st, (const half_t*)in_hi, (const half_t*)in_lo,
+                       (half_t*)out_hi, (half_t*)out_lo, B, hin, cin_p, cout_p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+int mpx_geometry(const mpx_engine* h, int* image_size, int* in_channels, int* num_classes, int* logit_pitch) {
+    if (!h) return MPX_E_ARG;
+    if (image_size) *image_size = h->img;
+    if (in_channels) *in_channels = h->in_ch;
+    if (num_classes) *num_classes = h->ncls;
+    if (logit_pitch) *logit_pitch = h->logit_pitch;
+    return 0;
+}
+
 int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* res_hi, const void* res_lo,
                     void* out_hi, void* out_lo, float* out_f32, int B, void* stream) {
     if (!h) return MPX_E_ARG;
@@ -746,6 +941,10 @@ int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, 
     const ConvLayer& L = h->convs[i];
     if (L.is_stem) {
         if (in_hi || in_lo) return fail(h, MPX_E_ARG, "conv_bn_act: layer 0 reads the engine input staging; pass NULL inputs");
+        if (B > h->max_batch) return fail(h, MPX_E_STATE, "conv_bn_act: B > max_batch");
+    } else if (h->small && i == 0 && !in_hi && !in_lo) {
+        in_hi = h->in_hi;               // the small networks' first conv reads the engine's [B][H][W][32] staging
+        in_lo = h->in_lo;
         if (B > h->max_batch) return fail(h, MPX_E_STATE, "conv_bn_act: B > max_batch");
     } else if (!in_hi || !in_lo) {
         return fail(h, MPX_E_ARG, "conv_bn_act: null input planes");
@@ -797,7 +996,7 @@ int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* l
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 3, -1);
     hipLaunchKernelGGL(head_softmax_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, label, score, pred, B,
-                       MPX_NUM_CLASSES);
+                       h->ncls, h->logit_pitch);
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
@@ -809,6 +1008,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     if (B > h->max_batch) return fail(h, MPX_E_STATE, "forward: B=%d exceeds max_batch=%d", B, h->max_batch);
     if (mpx_weights_complete(h) != 1) return fail(h, MPX_E_STATE, "forward: weights not loaded for every layer");
     float* logits = logits_out ? logits_out : h->logits;
+    // (BUF_INPUT stays NULL: layer 0 reads the engine's own staging, mpx_conv_bn_act)
     auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b >= 0 ? h->act_hi[b] : nullptr); };
     auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
     int rc = 0;
@@ -832,6 +1032,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
             case OP_MAXPOOL: rc = mpx_maxpool3x3s2(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c, stream); break;
             case OP_AVGPOOL: rc = mpx_global_avgpool(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin * o.hin, o.c, stream); break;
             case OP_HEAD: rc = mpx_head_softmax_gather(h, logits, label, score, pred, B, stream); break;
+            case OP_AVGPAD: rc = mpx_avgpool2_pad(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c >> 16, o.c & 0xffff, stream); break;
         }
         if (rc) return rc;
     }
@@ -865,7 +1066,7 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
     hipLaunchKernelGGL(heatmap_segment_count_kernel, dim3((S + 255) / 256), dim3(256), 0, st, onoff, pred, label, M, S,
                        h->seg_scratch);
     MPX_HIP(h, hipGetLastError());
-    const int npix = MPX_IMG * MPX_IMG;
+    const int npix = h->img * h->img;
     hipLaunchKernelGGL(heatmap_gather_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, seg, h->seg_scratch, S, npix, heat);
     MPX_HIP(h, hipGetLastError());
     return 0;

@@ -268,14 +268,17 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[2 * q][b][j]),
-                                                                      __builtin_bit_cast(unsigned, acc[2 * q + 1][b][j]), false, false);
-                    v[j] = __builtin_bit_cast(float, (unsigned)sw[0]) * sc[q][0][j] + sh[q][0][j];
-                    v[4 + j] = __builtin_bit_cast(float, (unsigned)sw[1]) * sc[q][1][j] + sh[q][1][j];
+                    // (copy the vector elements into scalars first: __builtin_bit_cast applied to an ext_vector element
+                    // lvalue reads element 0 whatever the subscript -- clang 22 / ROCm 7.2)
+                    const float ea = acc[2 * q][b][j], eb = acc[2 * q + 1][b][j];
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(ea), __float_as_uint(eb), false, false);
+                    v[j] = __uint_as_float((unsigned)sw[0]) * sc[q][0][j] + sh[q][0][j];
+                    v[4 + j] = __uint_as_float((unsigned)sw[1]) * sc[q][1][j] + sh[q][1][j];
                 }
                 if (p.r_hi) {
-                    const h8 a = __builtin_bit_cast(h8, rh[q][b]);
-                    const h8 c = __builtin_bit_cast(h8, rl[q][b]);
+                    const u4 ra = rh[q][b], rc = rl[q][b];
+                    const h8 a = __builtin_bit_cast(h8, ra);
+                    const h8 c = __builtin_bit_cast(h8, rc);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += (float)a[j] + (float)c[j];
                 }
@@ -344,7 +347,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
             prologue();
         }
         epilogue(m0e, n0e);
-        if (!more) break;
+        if (!more) {
+            // the trailing dead DMAs of the K loop still target this workgroup's LDS: they are older than the stores, so they
+            // have retired when at most the stores are outstanding (the LDS may be handed to another workgroup after s_endpgm)
+            wait_vmcnt<N_STORES>();
+            break;
+        }
         vb = vbn;
         // the N_STORES stores are this wave's youngest vector-memory instructions: everything older -- the residual loads and
         // the whole prologue of the new tile -- has retired when at most they are outstanding

@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void head_softmax_gather_kernel(const float* _
                                                                   const int32_t* __restrict__ label,
                                                                   float* __restrict__ score,
                                                                   int32_t* __restrict__ pred, int B,
-                                                                  int ncls) {
+                                                                  int ncls, int pitch) {
     const int lane = threadIdx.x & 63;
     const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (img >= B) return;
-    const float* row = logits + (size_t)img * ncls;
+    const float* row = logits + (size_t)img * pitch;
     float mx = -INFINITY;
     int arg = 0;
     for (int i = lane; i < ncls; i += 64) {
@@ -209,6 +209,155 @@ __global__ __launch_bounds__(256) void head_softmax_gather_kernel(const float* _
         score[img] = ok ? __fdiv_rn(expf(row[lb] - mx), sum) : 0.f;
         pred[img] = arg;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// DownsampleB of the reference's CIFAR ResNet (models/resnet.py:64-74): AvgPool2d(2) on the identity, then zero
+// channels up to the block's width.  Planes [B][hin][hin][cin_p] -> [B][hin/2][hin/2][cout_p]; one thread = 8 channels
+// of one output pixel; the four taps are summed in torch's order (row-major) and divided by 4 in fp32.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_pad_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
+                                                           half_t* __restrict__ out_hi, half_t* __restrict__ out_lo, int B,
+                                                           int hin, int cin_p, int cout_p) {
+    const int ho = hin / 2, cg = cout_p / 8;
+    const size_t total = (size_t)B * ho * ho * cg;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int g = (int)(t % cg);
+        size_t r = t / cg;
+        const int ox = (int)(r % ho);
+        r /= ho;
+        const int oy = (int)(r % ho);
+        const int n = (int)(r / ho);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (g * 8 < cin_p) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t o = (((size_t)n * hin + oy * 2 + dy) * hin + ox * 2 + dx) * cin_p + g * 8;
+                    const h8 vh = *(const h8*)(in_hi + o);
+                    const h8 vl = *(const h8*)(in_lo + o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = __fadd_rn(acc[j], (float)vh[j] + (float)vl[j]);
+                }
+        }
+        h8 oh, ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t hi, lo;
+            split_f32(__fdiv_rn(acc[j], 4.0f), hi, lo);
+            oh[j] = hi;
+            ol[j] = lo;
+        }
+        const size_t o = (((size_t)n * ho + oy) * ho + ox) * cout_p + g * 8;
+        *(h8*)(out_hi + o) = oh;
+        *(h8*)(out_lo + o) = ol;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K0 of the small networks: the CIFAR / MNIST scorers' mask convention (generate_gp_training_data_cifar.py:274-321,
+// generate_gp_training_data_mnist.py:167-242): the picture is min-max scaled to [0,255] in place (x255), the SELECTED
+// superpixels are switched OFF by a {0,255} mask, the product is min-max scaled to [0,255] again and multiplied by
+// f32(1/255).  min(x255 * mask) is exactly 0 (x255 contains an exact 0, and 0 * anything = 0), so the second rescale
+// only needs max over the KEPT pixels of fl(x255 * 255) = fl(255 * max kept x255): per-superpixel maxima once per image,
+// then a max over each mask's kept superpixels.  Every fp32 operation is rounded in the reference's order.
+//   stats[0] = min(x), stats[1] = fl(max(x) - min(x)), stats[2 .. 2+S) = per-superpixel max of x255, then per-mask max.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float minmax255(float x, float mn, float range) {
+    return __fmul_rn(__fdiv_rn(__fsub_rn(x, mn), range), 255.0f);
+}
+
+__global__ __launch_bounds__(256) void smallnet_image_stats_kernel(const float* __restrict__ img, const int32_t* __restrict__ seg,
+                                                                   int C, int hw, int S, float* __restrict__ stats) {
+    __shared__ float s_mn[256], s_mx[256];
+    __shared__ unsigned s_seg[4096];
+    const int tid = threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < C * hw; i += 256) {
+        const float v = img[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    s_mn[tid] = mn;
+    s_mx[tid] = mx;
+    for (int i = tid; i < S; i += 256) s_seg[i] = 0u;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            s_mn[tid] = fminf(s_mn[tid], s_mn[tid + o]);
+            s_mx[tid] = fmaxf(s_mx[tid], s_mx[tid + o]);
+        }
+        __syncthreads();
+    }
+    const float gmn = s_mn[0];
+    const float range = __fsub_rn(s_mx[0], gmn);       // = max(x - min): subtraction is monotonic
+    for (int i = tid; i < C * hw; i += 256) {
+        const int sgm = seg[i % hw];
+        if ((unsigned)sgm < (unsigned)S) atomicMax(&s_seg[sgm], __float_as_uint(minmax255(img[i], gmn, range)));   // values >= 0
+    }
+    __syncthreads();
+    if (tid == 0) {
+        stats[0] = gmn;
+        stats[1] = range;
+    }
+    for (int i = tid; i < S; i += 256) stats[2 + i] = __uint_as_float(s_seg[i]);
+}
+
+__global__ __launch_bounds__(256) void smallnet_mask_max_kernel(const uint8_t* __restrict__ removed, int M, int S,
+                                                                const float* __restrict__ stats, float* __restrict__ mask_max) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float mx = 0.f;                                     // removed pixels contribute 0 * x = 0
+    for (int sgm = 0; sgm < S; ++sgm)
+        if (!removed[(size_t)m * S + sgm]) mx = fmaxf(mx, stats[2 + sgm]);
+    mask_max[m] = __fmul_rn(mx, 255.0f);                // max over pixels of fl(x255 * 255) (the product is monotonic)
+}
+
+struct SmallMaskParams {
+    const float* img;        // [C][H][W] as the loader yields it
+    const int32_t* seg;      // [H][W] ranks
+    const uint8_t* removed;  // [M][S], 1 = superpixel switched off
+    const float* stats;      // smallnet_image_stats_kernel
+    const float* mask_max;   // [M]
+    half_t* out_hi;          // staging [slot][H][W][32]
+    half_t* out_lo;
+    float* out_f32;          // [M][C][H][W] or null
+    int C, hw, M, S, slot0;
+};
+
+__global__ __launch_bounds__(256) void smallnet_mask_apply_kernel(const SmallMaskParams p) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (pix >= p.hw) return;
+    const int sgm = p.seg[pix];
+    const bool keep = (unsigned)sgm < (unsigned)p.S && !p.removed[(size_t)m * p.S + sgm];
+    const float mmax = p.mask_max[m];
+    h8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        oh[j] = (half_t)0.f;
+        ol[j] = (half_t)0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c >= p.C) break;
+        const float x255 = minmax255(p.img[(size_t)c * p.hw + pix], p.stats[0], p.stats[1]);
+        const float a = __fmul_rn(x255, keep ? 255.0f : 0.0f);          // org_img * mask
+        const float b = __fsub_rn(a, 0.0f);                             // masked -= masked.min()  (the minimum is exactly 0)
+        const float d = __fmul_rn(__fdiv_rn(b, mmax), 255.0f);          // /= max; *= 255
+        const float v = __fmul_rn(d, 0.003921568859368563f);            // normalize_image: * f32(1/255)
+        half_t hi, lo;
+        split_f32(v, hi, lo);
+        oh[c] = hi;
+        ol[c] = lo;
+        if (p.out_f32) p.out_f32[((size_t)m * p.C + c) * p.hw + pix] = v;
+    }
+    const size_t so = ((size_t)(p.slot0 + m) * p.hw + pix) * 32;
+    *(h8*)(p.out_hi + so) = oh;        // channels [0,8) of the 32 per pixel; the rest stay zero from mpx_create
+    *(h8*)(p.out_lo + so) = ol;
 }
 
 // ------------------------------------------------------------------------------------------

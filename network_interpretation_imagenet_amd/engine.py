@@ -21,7 +21,9 @@ MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 BN_EPS = 1e-5   # torchvision BatchNorm2d default
 
-ARCH_IDS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnet101": 101, "resnet152": 152}
+ARCH_IDS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnet101": 101, "resnet152": 152,
+            # the reference's two small networks (include/mpx.h MPX_ARCH_*)
+            "mnist_net": 1, "cifar_resnet20": 2020, "cifar_resnet56": 2056, "cifar_resnet110": 2110}
 
 
 class BasePredictionWrong(Exception):
@@ -56,7 +58,7 @@ class MaskedForwardEngine:
 
     def __init__(self, arch="resnet101", max_batch=512, device=None):
         if arch not in ARCH_IDS:
-            raise ValueError("unsupported arch %r (torchvision ResNets only: %s)" % (arch, sorted(ARCH_IDS)))
+            raise ValueError("unsupported arch %r (torchvision ResNets and the reference's small networks: %s)" % (arch, sorted(ARCH_IDS)))
         if not torch.cuda.is_available():
             raise MpxError("no MI355X visible: the scorer has no CPU path")
         self._lib = _lib.load()
@@ -75,6 +77,10 @@ class MaskedForwardEngine:
             self.layers.append(d)
         self.flops_per_forward = float(self._lib.mpx_flops_per_forward(h))
         self._mean, self._std = _f3(MEAN), _f3(STD)
+        g = [C.c_int() for _ in range(4)]
+        _lib.check(h, self._lib.mpx_geometry(h, *[C.byref(v) for v in g]), "mpx_geometry")
+        self.image_size, self.in_channels, self.num_classes, self.logit_pitch = (int(v.value) for v in g)
+        self.small = self.image_size != IMG
 
     # ---- life cycle ----
     def close(self):
@@ -116,17 +122,18 @@ class MaskedForwardEngine:
 
         for i, d in enumerate(self.layers):
             name, bn = d.name.decode(), d.bn_name.decode()
-            if name == "fc":
-                w = get("fc.weight", (NUM_CLASSES, d.cin))
-                b = get("fc.bias", (NUM_CLASSES,))
-                args = (_ptr(w), None, _ptr(b), None, None)
+            wshape = (d.cout, d.cin) if (d.ksize == 1 and sd[name + ".weight"].dim() == 2) else (d.cout, d.cin, d.ksize, d.ksize)
+            w = get(name + ".weight", wshape)
+            if not bn:          # no BatchNorm: fc, or the MNIST net's conv6 -- the layer's own bias goes in as `beta`
+                b = get(name + ".bias", (d.cout,))
+                args = (_ptr(w), None, None, _ptr(b), None, None)
             else:
-                w = get(name + ".weight", (d.cout, d.cin, d.ksize, d.ksize))
+                cb = get(name + ".bias", (d.cout,)) if (name + ".bias") in sd else None      # nn.Conv2d(bias=True) + BN
                 g = get(bn + ".weight", (d.cout,))
                 b = get(bn + ".bias", (d.cout,))
                 m = get(bn + ".running_mean", (d.cout,))
                 v = get(bn + ".running_var", (d.cout,))
-                args = (_ptr(w), _ptr(g), _ptr(b), _ptr(m), _ptr(v))
+                args = (_ptr(w), _ptr(cb), _ptr(g), _ptr(b), _ptr(m), _ptr(v))
             _lib.check(self._h, self._lib.mpx_set_conv_weights(self._h, i, *args, float(eps)),
                        "mpx_set_conv_weights(%s)" % name)
         return self
@@ -171,10 +178,10 @@ class MaskedForwardEngine:
                 raise ValueError("%s must be contiguous %s[%d] on %s" % (name, dt, batch, self.device))
         score = score_out if score_out is not None else torch.empty(batch, dtype=torch.float32, device=self.device)
         pred = pred_out if pred_out is not None else torch.empty(batch, dtype=torch.int32, device=self.device)
-        logits = torch.empty(batch, NUM_CLASSES, dtype=torch.float32, device=self.device) if want_logits else None
+        logits = torch.empty(batch, self.logit_pitch, dtype=torch.float32, device=self.device) if want_logits else None
         _lib.check(self._h, self._lib.mpx_forward(self._h, _ptr(labels), _ptr(score), _ptr(pred), _ptr(logits),
                                                   int(batch), self._stream()), "mpx_forward")
-        return (score, pred, logits) if want_logits else (score, pred)
+        return (score, pred, logits[:, :self.num_classes]) if want_logits else (score, pred)
 
     def input_planes(self, n=None):
         """Zero-copy fp16 views [n,230,230,4] of the engine-owned padded NHWC4 input staging planes
@@ -206,11 +213,66 @@ class MaskedForwardEngine:
             raise ValueError("image must be uint8 HWC or float32 CHW, got %s" % t.dtype)
         return t.contiguous().to(self.device)
 
+    def score_masks_removed(self, image_chw, segments, removed, label, return_logits=False, return_inputs=False):
+        """The small networks' scorer: (image f32[C,H,W] as the loader yields it, segments int[H,W],
+        removed u8[M,S] with 1 = superpixel switched OFF, label) -> (removed, score f32[M], pred i32[M][, logits][, inputs]).
+        The mask convention is generate_gp_training_data_cifar.py:274-321 / generate_gp_training_data_mnist.py:167-242:
+        min-max the picture to [0,255], multiply by the {0,255} mask, min-max again, * f32(1/255); pred[m] is the reference's
+        `pred_mask`, score[m] the softmax probability of `label`."""
+        if not self.small:
+            raise ValueError("score_masks_removed is the small networks' convention; %s uses score_masks" % self.arch)
+        x = torch.as_tensor(image_chw)
+        if x.dim() == 4 and x.shape[0] == 1:
+            x = x[0]
+        n = self.image_size
+        if x.dtype != torch.float32 or tuple(x.shape) != (self.in_channels, n, n):
+            raise ValueError("image must be float32[%d,%d,%d], got %s%s" % (self.in_channels, n, n, x.dtype, tuple(x.shape)))
+        seg = np.asarray(segments)
+        if seg.shape != (n, n) or not np.issubdtype(seg.dtype, np.integer):
+            raise ValueError("segments must be an integer [%d,%d] label map" % (n, n))
+        uniq, inv = np.unique(seg, return_inverse=True)
+        s = int(len(uniq))
+        removed = np.ascontiguousarray(removed)
+        if removed.dtype != np.uint8 or removed.ndim != 2 or removed.shape[1] != s:
+            raise ValueError("removed must be uint8[M,%d], got %s%s" % (s, removed.dtype, removed.shape))
+        if not 0 <= int(label) < self.num_classes:
+            raise ValueError("label %r outside [0,%d)" % (label, self.num_classes))
+        m = removed.shape[0]
+        score = np.empty(m, dtype=np.float32)
+        pred = np.empty(m, dtype=np.int32)
+        logits = np.empty((m, self.num_classes), dtype=np.float32) if return_logits else None
+        inputs = np.empty((m, self.in_channels, n, n), dtype=np.float32) if return_inputs else None
+        x_d = x.contiguous().to(self.device)
+        seg_d = torch.from_numpy(inv.reshape(n, n).astype(np.int32)).to(self.device)
+        rem_d = torch.from_numpy(removed).to(self.device)
+        for s0 in range(0, m, self.max_batch):
+            b = min(self.max_batch, m - s0)
+            labels = torch.full((b,), int(label), dtype=torch.int32, device=self.device)
+            out_f32 = torch.empty(b, self.in_channels, n, n, dtype=torch.float32, device=self.device) if return_inputs else None
+            _lib.check(self._h, self._lib.mpx_mask_apply_minmax(self._h, _ptr(x_d), _ptr(seg_d), _ptr(rem_d[s0:s0 + b].contiguous()),
+                                                                int(b), int(s), 0, _ptr(out_f32), self._stream()),
+                       "mpx_mask_apply_minmax")
+            out = self.forward(b, labels, want_logits=return_logits)
+            score[s0:s0 + b] = out[0].cpu().numpy()
+            pred[s0:s0 + b] = out[1].cpu().numpy()
+            if return_logits:
+                logits[s0:s0 + b] = out[2].cpu().numpy()
+            if return_inputs:
+                inputs[s0:s0 + b] = out_f32.cpu().numpy()
+        res = (removed, score, pred)
+        if return_logits:
+            res += (logits,)
+        if return_inputs:
+            res += (inputs,)
+        return res
+
     def score_masks(self, image, segments, onoff, label, return_logits=False):
         """(image, segments, onoff u8[M,S], label) -> (onoff u8[M,S], score f32[M], pred i32[M]).
         score[m] = softmax(model(normalised_image * mask_m))[label]
         (bayesian_active_learning_imagenet.py:187-198); pred[m] == label is the generators' binary
         label (generate_gp_training_data_imagenet.py:248,257)."""
+        if self.small:
+            raise ValueError("%s scores with score_masks_removed (the small networks' mask convention)" % self.arch)
         seg_rank, s = rank_segments(segments)
         onoff = np.ascontiguousarray(onoff)
         if onoff.dtype != np.uint8 or onoff.ndim != 2 or onoff.shape[1] != s:

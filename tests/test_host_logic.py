@@ -76,13 +76,13 @@ def _desc(cin, cout, k):
     return d
 
 
-def _pack(mpx_lib, d, w, bn):
+def _pack(mpx_lib, d, w, bn, bias=None):
     hi = np.zeros((d.cout_pad, d.k_packed), dtype=np.uint16)
     lo = np.zeros_like(hi)
     sc = np.zeros(d.cout_pad, dtype=np.float32)
     sh = np.zeros(d.cout_pad, dtype=np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-    rc = mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5,
+    rc = mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(bias), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5,
                                        p(hi), p(lo), p(sc), p(sh))
     assert rc == 0
     return hi.view(np.float16), lo.view(np.float16), sc, sh
@@ -136,7 +136,32 @@ def test_pack_rejects_bad_desc(mpx_lib):
     z = np.zeros(64, dtype=np.float32)
     buf = np.zeros((128, 576), dtype=np.uint16)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    assert mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(z), p(z), p(z), p(z), 1e-5, p(buf), p(buf), p(z), p(z)) == -1
+    assert mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), None, p(z), p(z), p(z), p(z), 1e-5, p(buf), p(buf), p(z), p(z)) == -1
+
+
+def test_pack_padded_channels_and_conv_bias(mpx_lib):
+    """The small networks' layers: input planes carry cin_pad = 32 channels per pixel for a 16- (or 1-) channel layer, and
+    the MNIST net's convs have their own bias in front of the BatchNorm: shift = beta + (bias - mean) * s."""
+    rng = np.random.default_rng(4)
+    cin, cout, k, cin_pad = 16, 16, 3, 32
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
+          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2, cout).astype(np.float32)]
+    d = _lib.ConvDesc()
+    d.cin, d.cout, d.ksize = cin, cout, k
+    d.k_packed = k * k * cin_pad
+    d.cout_pad = 128
+    hi, lo, sc, sh = _pack(mpx_lib, d, w, bn, bias)
+    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
+    np.testing.assert_allclose(sh[:cout], bn[1] + (bias.astype(np.float64) - bn[2]) * s, rtol=1e-6, atol=1e-7)
+    planes = (hi[:cout].astype(np.float64) + lo[:cout]).reshape(cout, k * k, cin_pad) * sc[:cout, None, None].astype(np.float64) / s[:, None, None]
+    np.testing.assert_allclose(planes[:, :, :cin], w.transpose(0, 2, 3, 1).reshape(cout, k * k, cin), rtol=0, atol=1e-6)
+    assert (planes[:, :, cin:] == 0).all() and (hi[cout:] == 0).all() and (sc[cout:] == 0).all()
+    d.k_packed = k * k * 8                             # fewer plane channels than the layer reads
+    buf = np.zeros((128, k * k * 32), dtype=np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), None, p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5, p(buf), p(buf), p(sc), p(sh)) == -1
 
 
 def test_rank_segments():
