@@ -95,6 +95,7 @@ struct mpx_engine {
     float* logits = nullptr;
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
+    bool in_forward = false;
     bool fuse_ds = true;    // mpx_forward runs a block's last conv and its downsample conv as one launch (mpx_set_fusion)
     bool prof_on = false;
     std::vector<ProfRec> prof_pool;
@@ -125,6 +126,12 @@ int fail(mpx_engine* h, int code, const char* fmt, ...) {
         if (e_ != hipSuccess)                                                                    \
             return fail((h), (int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
                         __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// every entry point selects the engine's device; mpx_forward does it ONCE and runs its ~110 launches without the call
+#define MPX_SET_DEVICE(h)                                   \
+    do {                                                    \
+        if (!(h)->in_forward) MPX_HIP((h), hipSetDevice((h)->device)); \
     } while (0)
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -806,7 +813,7 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv
     std::vector<float> sc(L.d.cout_pad), sh(L.d.cout_pad);
     int rc = mpx_pack_conv_weights(&L.d, w, conv_bias, gamma, beta, mean, var, eps, hi.data(), lo.data(), sc.data(), sh.data());
     if (rc) return fail(h, rc, "pack failed for %s", L.d.name);
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     MPX_HIP(h, hipMemcpy(L.w_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.w_lo, lo.data(), n * 2, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
@@ -874,7 +881,7 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
     }
     p.M = M; p.S = S; p.slot0 = slot0;
     p.size = MPX_IMG; p.pad_size = MPX_IMG_PAD; p.border = 3;
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 1, -1);
     dim3 grid((MPX_IMG * MPX_IMG + 255) / 256, (M + K0_MT - 1) / K0_MT);
@@ -889,7 +896,7 @@ int mpx_mask_apply_minmax(mpx_engine* h, const float* img_f32_chw, const int32_t
     if (!h->small) return fail(h, MPX_E_STATE, "mask_apply_minmax: only the small networks (MNIST net, CIFAR ResNet) use this mask convention");
     if (!img_f32_chw || !seg || !removed || M <= 0 || S <= 0 || S > 4096) return fail(h, MPX_E_ARG, "mask_apply_minmax: null input, empty M/S or S > 4096");
     if (slot0 < 0 || slot0 + M > h->max_batch) return fail(h, MPX_E_STATE, "mask_apply_minmax: slots [%d,%d) exceed max_batch %d", slot0, slot0 + M, h->max_batch);
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 1, -1);
     const int hw = h->img * h->img;
@@ -914,7 +921,7 @@ int mpx_avgpool2_pad(mpx_engine* h, const void* in_hi, const void* in_lo, void* 
     if (!h) return MPX_E_ARG;
     if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hin <= 0 || (hin & 1) || cin_p <= 0 || (cin_p & 7) || cout_p < cin_p || (cout_p & 7))
         return fail(h, MPX_E_ARG, "avgpool2_pad: bad arguments (hin even, channel counts multiples of 8, cout_p >= cin_p)");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 2, -1);
     const size_t total = (size_t)B * (hin / 2) * (hin / 2) * (cout_p / 8);
@@ -952,7 +959,7 @@ int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, 
     if ((res_hi == nullptr) != (res_lo == nullptr)) return fail(h, MPX_E_ARG, "conv_bn_act: residual planes must come in pairs");
     if (L.is_fc ? (out_f32 == nullptr) : (out_f32 != nullptr || !out_hi || !out_lo))
         return fail(h, MPX_E_ARG, "conv_bn_act: fc writes out_f32, every other layer writes out_hi/out_lo");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     return launch_conv(h, i, (const half_t*)in_hi, (const half_t*)in_lo, (const half_t*)res_hi, (const half_t*)res_lo,
                        (half_t*)out_hi, (half_t*)out_lo, out_f32, B, as_stream(stream));
 }
@@ -962,7 +969,7 @@ int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* 
     if (!h) return MPX_E_ARG;
     if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hin <= 0 || (hin & 1) || c <= 0 || (c & 7))
         return fail(h, MPX_E_ARG, "maxpool3x3s2: bad arguments (hin even, c multiple of 8)");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 2, -1);
     const size_t total = (size_t)B * (hin / 2) * (hin / 2) * (c / 8);
@@ -978,7 +985,7 @@ int mpx_global_avgpool(mpx_engine* h, const void* in_hi, const void* in_lo, void
     if (!h) return MPX_E_ARG;
     if (!in_hi || !in_lo || !out_hi || !out_lo || B <= 0 || hw <= 0 || c <= 0 || (c & 7))
         return fail(h, MPX_E_ARG, "global_avgpool: bad arguments (c multiple of 8)");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 2, -1);
     const int total = B * (c / 8);
@@ -992,7 +999,7 @@ int mpx_head_softmax_gather(mpx_engine* h, const float* logits, const int32_t* l
                             int B, void* stream) {
     if (!h) return MPX_E_ARG;
     if (!logits || !label || !score || !pred || B <= 0) return fail(h, MPX_E_ARG, "head_softmax_gather: null pointer or empty batch");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     ProfScope ps(h, st, 3, -1);
     hipLaunchKernelGGL(head_softmax_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, label, score, pred, B,
@@ -1008,6 +1015,12 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     if (B > h->max_batch) return fail(h, MPX_E_STATE, "forward: B=%d exceeds max_batch=%d", B, h->max_batch);
     if (mpx_weights_complete(h) != 1) return fail(h, MPX_E_STATE, "forward: weights not loaded for every layer");
     float* logits = logits_out ? logits_out : h->logits;
+    MPX_HIP(h, hipSetDevice(h->device));
+    struct InForward {
+        mpx_engine* e;
+        explicit InForward(mpx_engine* e_) : e(e_) { e->in_forward = true; }
+        ~InForward() { e->in_forward = false; }
+    } scope(h);
     // (BUF_INPUT stays NULL: layer 0 reads the engine's own staging, mpx_conv_bn_act)
     auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b >= 0 ? h->act_hi[b] : nullptr); };
     auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
@@ -1051,7 +1064,7 @@ int mpx_conv_dual_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in
     if (i < 0 || i >= (int)h->convs.size() || B <= 0) return fail(h, MPX_E_ARG, "conv_dual_bn_act: bad layer index or batch");
     if (!h->convs[i].fuse_main) return fail(h, MPX_E_ARG, "conv_dual_bn_act: layer %d (%s) is not the last conv of a block with a downsample branch", i, h->convs[i].d.name);
     if (!in_hi || !in_lo || !x_hi || !x_lo || !out_hi || !out_lo) return fail(h, MPX_E_ARG, "conv_dual_bn_act: null planes");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     return launch_conv_fused(h, i, (const half_t*)in_hi, (const half_t*)in_lo, (const half_t*)x_hi, (const half_t*)x_lo,
                              (half_t*)out_hi, (half_t*)out_lo, B, as_stream(stream));
 }
@@ -1061,7 +1074,7 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
     if (!h) return MPX_E_ARG;
     if (!seg || !onoff || !pred || !label || !heat || M <= 0 || S <= 0 || S > 4096)
         return fail(h, MPX_E_ARG, "heatmap_accumulate: null pointer, empty M/S or S > 4096");
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(heatmap_segment_count_kernel, dim3((S + 255) / 256), dim3(256), 0, st, onoff, pred, label, M, S,
                        h->seg_scratch);
@@ -1082,7 +1095,7 @@ int mpx_input_planes(const mpx_engine* h, void** hi, void** lo) {
 int mpx_profile_enable(mpx_engine* h, int on) {
     if (!h) return MPX_E_ARG;
     if (on && h->prof_pool.empty()) {
-        MPX_HIP(h, hipSetDevice(h->device));
+        MPX_SET_DEVICE(h);
         h->prof_pool.resize(kProfilePairs);
         for (ProfRec& r : h->prof_pool) {
             MPX_HIP(h, hipEventCreate(&r.t0));
@@ -1096,7 +1109,7 @@ int mpx_profile_enable(mpx_engine* h, int on) {
 int mpx_profile_collect(mpx_engine* h, double ms_by_kind[4], long long launches_by_kind[4], double* per_conv_ms) {
     if (!h || !ms_by_kind || !launches_by_kind) return MPX_E_ARG;
     if (h->prof_used == 0) return 0;
-    MPX_HIP(h, hipSetDevice(h->device));
+    MPX_SET_DEVICE(h);
     MPX_HIP(h, hipEventSynchronize(h->prof_pool[h->prof_used - 1].t1));
     for (int i = 0; i < h->prof_used; ++i) {
         ProfRec& r = h->prof_pool[i];

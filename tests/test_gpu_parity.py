@@ -716,3 +716,74 @@ def test_engine_errors(eng18, dev):
     with pytest.raises(KeyError):
         fresh.load_state_dict({})
     fresh.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's two small networks, WHOLE TRAINED nets (shipped checkpoints) on the HIP kernels
+# ------------------------------------------------------------------------------------------------
+def _smallnet_case(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, "smallnet_%s.npz" % arch))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    return g, sd
+
+
+@pytest.mark.parametrize("arch", ["mnist_net", "cifar_resnet56"])
+def test_trained_small_network_end_to_end(mpx_lib, dev, golden_dir, arch):
+    """Classification_Net (generate_gp_training_data_mnist.py:86-105) and ResNetCifar(56) (models/resnet.py:77-146) with
+    the weights of the reference's own checkpoints, scored under the CIFAR / MNIST scorers' mask convention
+    (generate_gp_training_data_cifar.py:274-321): the staged network inputs must equal the oracle's NumPy arithmetic bit for
+    bit, logits / scores agree with the CPU oracle within the score tolerance, argmax exactly."""
+    from oracle import smallnets_ref
+    g, sd = _smallnet_case(arch, golden_dir)
+    eng = MaskedForwardEngine(arch, max_batch=16, device=0).load_state_dict(sd)      # 24 masks: two chunks
+    try:
+        assert (eng.image_size, eng.in_channels, eng.num_classes) == ((28, 1, 10) if arch == "mnist_net" else (32, 3, 10))
+        worst_logit = worst_score = 0.0
+        for i in range(int(g["n_pictures"])):
+            p = "pic%d/" % i
+            x, seg, removed, label = g[p + "x"], g[p + "segments"], g[p + "removed"], int(g[p + "label"])
+            _r, score, pred, logits, inputs = eng.score_masks_removed(x, seg, removed, label, return_logits=True, return_inputs=True)
+            assert (inputs.view(np.int32) == g[p + "masked_inputs"].view(np.int32)).all(), "K0 (min-max mask convention) is not bit-exact"
+            want = g[p + "masked_logits_f32"]
+            worst_logit = max(worst_logit, float(np.abs(logits - want).max() / max(1.0, np.abs(want).max())))
+            worst_score = max(worst_score, float(np.abs(score - g[p + "score_f32"]).max()))
+            assert (pred == g[p + "pred"]).all()
+            assert np.abs(logits.astype(np.float64) - g[p + "masked_logits_f64"]).max() <= 1e-4
+            # live oracle on three masks (the fixture pins the oracle; this pins the test's reading of it)
+            uniq = np.unique(seg)
+            lists = [[int(uniq[j]) for j in np.nonzero(row)[0]] for row in removed[:3]]
+            ref_score, ref_pred = smallnets_ref.score_removed_loop(sd, arch, x, seg, lists, label)
+            assert np.abs(score[:3] - ref_score).max() <= SCORE_TOL_TIGHT and (pred[:3] == ref_pred).all()
+        print("%s trained: max rel logit err %.3e, max |d score| %.3e" % (arch, worst_logit, worst_score))
+        assert worst_logit <= 1e-5 and worst_score <= SCORE_TOL_TIGHT
+        with pytest.raises(ValueError):
+            eng.score_masks(np.zeros((224, 224, 3), dtype=np.uint8), np.zeros((224, 224), dtype=np.int32), np.ones((1, 1), dtype=np.uint8), 0)
+    finally:
+        eng.close()
+
+
+def test_small_network_ops(mpx_lib, dev, golden_dir):
+    """DownsampleB (mpx_avgpool2_pad) exactly, and a mask that removes every superpixel gives NaN inputs as 0/0 does upstream."""
+    g, sd = _smallnet_case("cifar_resnet56", golden_dir)
+    eng = MaskedForwardEngine("cifar_resnet56", max_batch=4, device=0).load_state_dict(sd)
+    try:
+        x = torch.randn(3, 16, 16, 32, generator=torch.Generator().manual_seed(4))
+        x[..., 16:] = 0
+        xh, xl = split(x.to(dev))
+        oh = torch.full((3, 8, 8, 32), float("nan"), dtype=torch.float16, device=dev)
+        ol = torch.full_like(oh, float("nan"))
+        _lib.check(eng._h, eng._lib.mpx_avgpool2_pad(eng._h, _p(xh), _p(xl), _p(oh), _p(ol), 3, 16, 32, 32, eng._stream()), "avgpool2_pad")
+        torch.cuda.synchronize()
+        want = F.avg_pool2d(merge(xh, xl).cpu().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert torch.equal(merge(oh, ol).cpu(), want)
+        assert eng._lib.mpx_avgpool2_pad(eng._h, _p(xh), _p(xl), _p(oh), _p(ol), 3, 15, 32, 32, None) == -1
+        p = "pic0/"
+        seg = g[p + "segments"]
+        S = len(np.unique(seg))
+        _r, score, pred, inputs = eng.score_masks_removed(g[p + "x"], seg, np.ones((1, S), dtype=np.uint8), 0, return_inputs=True)
+        assert np.isnan(inputs).all()
+        big = MaskedForwardEngine("resnet18", max_batch=1, device=0)
+        assert big._lib.mpx_mask_apply_minmax(big._h, None, None, None, 1, 1, 0, None, None) == -2      # ImageNet engines refuse it
+        big.close()
+    finally:
+        eng.close()
