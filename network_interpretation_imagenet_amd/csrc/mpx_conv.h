@@ -69,6 +69,7 @@ struct ConvParams {
     const half_t* x2_lo;
     int hin2, win2, pix_stride2, stride2;
     int k1;
+    int dbg;                 // experiment switches (MPX_DBG environment variable at mpx_create; 0 in production)
     int n_tiles;             // persistent kernels (mpx_convp.h): n_tiles_p * n_tiles_c, walked by a fixed grid
 #ifdef MPX_DIAG
     unsigned long long* stamps;   // diagnostic build only (tools/probes/conv_timeline.py): 8 u64 per workgroup

@@ -257,8 +257,13 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int b = 0; b < PF; ++b) {
-                    rh[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, off[q][b], 0, 2);      // nt: streamed once
-                    rl[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, off[q][b], 0, 2);
+                    if (p.dbg & 1) {
+                        rh[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, off[q][b], 0, 2);      // nt: streamed once
+                        rl[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, off[q][b], 0, 2);
+                    } else {
+                        rh[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, off[q][b], 0, 0);
+                        rl[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, off[q][b], 0, 0);
+                    }
                 }
         }
 #pragma unroll
@@ -294,8 +299,13 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
                     oh[j] = hi;
                     ol[j] = lo;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, off[q][b], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, off[q][b], 0, 0);
+                if (p.dbg & 2) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, off[q][b], 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, off[q][b], 0, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, off[q][b], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, off[q][b], 0, 0);
+                }
             }
         }
     };

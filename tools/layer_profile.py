@@ -18,6 +18,8 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda", 0)
 eng = MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(synth.make_state_dict(arch))
+if os.environ.get("MPX_NO_FUSION"):     # tool-only: run a stage's first conv3 and its downsample conv as two launches
+    eng.set_fusion(False)
 img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
 seg = torch.from_numpy(synth.grid_segments()).to(dev)
 onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
@@ -41,7 +43,7 @@ if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with clas
             cls = "k1s2"
         else:
             cls = "k1exp" if d.cout > d.cin else "k1red"
-        if cls in rules:
+        if cls in rules and d.name != b"fc":
             eng.set_conv_tile(i, int(rules[cls]))
 if os.environ.get("MPX_TILE_1X1"):      # tool-only override: one tile variant on every 1x1 conv with cout >= 128
     for i, d in enumerate(eng.layers):
@@ -78,7 +80,8 @@ for d, ms in zip(eng.layers, prof["per_conv_ms"]):
     tot += ms
 print("-- grouped by shape --")
 for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-    print("%5d->%-5d k%d s%d out%-4d x%-3d %8.3f ms %5.1f%% %8.1f TFLOP/s" % (key[0], key[1], key[2], key[3], key[4], n, ms, 100 * ms / tot, fl / ms / 1e9))
+    print("%5d->%-5d k%d s%d out%-4d x%-3d %8.3f ms %5.1f%% %8.1f TFLOP/s%s" % (key[0], key[1], key[2], key[3], key[4], n, ms, 100 * ms / tot, fl / max(ms, 1e-9) / 1e9,
+                                                                             "   (runs inside its block's conv3 launch)" if ms == 0 else ""))
 allfl = eng.flops_per_forward * batch
 print("conv total %.3f ms/batch -> %.1f TFLOP/s algorithmic; other kinds ms/batch: %s" % (
     tot, allfl / tot / 1e9, {k: round(v / reps, 3) for k, v in prof["ms"].items()}))
