@@ -406,7 +406,7 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     return 0;
 }
 
-// Persistent kernels (mpx_convp.h, tile ids 8 = the 128x128 4-wave tile, 9 = its 8-wave form): a fixed grid of
+// Persistent kernel (mpx_convp.h, tile id 8 = the 128x128 4-wave tile): a fixed grid of
 // MINB-per-CU workgroups walks all tiles.
 template <class Cfg, bool DUAL = false>
 int launch_convp_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
@@ -518,7 +518,6 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     }
     switch (L.tile) {
         case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
-        case 9: return launch_convp_tile<ConvTile7>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
@@ -558,7 +557,6 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
     ProfScope ps(h, st, OP_CONV, i);
     if (L.tile == 2) return launch_conv_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
     if (L.tile == 8) return launch_convp_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
-    if (L.tile == 9) return launch_convp_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
     return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
 }
 
@@ -761,10 +759,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::RING);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::RING);
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
@@ -841,9 +835,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 9) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
-    if (tile >= 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
-        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernels (8, 9) run conv layers with cout >= 128 (%s is not one)", L.d.name);
+    if (tile > 8) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
     if (tile == 6 && !patch_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;
@@ -1034,7 +1028,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 9)) {
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8)) {
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

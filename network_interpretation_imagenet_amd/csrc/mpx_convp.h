@@ -25,7 +25,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
     constexpr int TC = C::TC, TP = C::TP, NSW = C::NSW, NSX = C::NSX, NW = C::NW;
     constexpr int CF = C::CF, PF = C::PF, WJ = C::WJ, XJ = C::XJ, WSTAGE = C::WSTAGE, XSTAGE = C::XSTAGE, XBASE = C::XBASE;
     constexpr int OFF_WHI = 0, OFF_WLO = TC * 64, OFF_XHI = 0, OFF_XLO = TP * 64;
-    static_assert(CF % 2 == 0, "the register epilogue pairs cout fragments");
+    static_assert(CF % 4 == 0, "the register epilogue needs 64 output channels per wave (four cout fragments = one 128-B line)");
     constexpr int NQ = CF / 2;                                  // fragment pairs per wave
     constexpr int N_STORES = NQ * PF * 2;                       // epilogue store instructions per wave and tile
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -221,90 +221,115 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
     typedef std::integral_constant<bool, DUAL> SegLast;
 
     // ---- epilogue from the accumulator registers ---------------------------------------------------------------------
-    // After v_permlane16_swap(acc[2q][b][j], acc[2q+1][b][j]) a lane of row r = lane>>4 holds, for pixel column
-    // lane&15 of pixel fragment b, channels  fragment (2q + (r&1)) * 16 + (r>>1) * 8 + [0,8)  : [0,4) in acc[2q][b], [4,8) in
-    // acc[2q+1][b].  All loads / stores are buffer instructions; masked lanes carry an out-of-range offset, so every
-    // wave issues exactly N_STORES stores per tile.
+    // 1. v_permlane16_swap(acc[2q][b][j], acc[2q+1][b][j]): a lane of row r = lane>>4 then holds, for pixel column
+    //    lane&15 of pixel fragment b, the 8 consecutive channels  (2q + (r&1)) * 16 + (r>>1) * 8 + [0,8)  of its wave's range
+    //    ([0,4) in acc[2q][b], [4,8) in acc[2q+1][b]): 16 B per plane.  One pair q covers 32 channels = 64 B of a pixel row.
+    // 2. Half-line (64-B) accesses cost ~1.4x the HBM time of full lines (measured: 64->256 at 60 instead of 84 TFLOP/s), so
+    //    two pairs (qe, qo) = 64 channels = one 128-B line are regrouped with two DPP moves per register (row_ror:8, bank
+    //    masks): instruction A carries pixels [0,8) of the fragment -- lanes 0-7 of a row keep pair qe, lanes 8-15 receive
+    //    pair qo of the pixel 8 lanes below -- and instruction B pixels [8,16) the other way round.  Every load / store
+    //    instruction then moves 8 pixel rows x 128 B.
+    // All loads / stores are buffer instructions; masked lanes carry an out-of-range offset, so every wave issues exactly
+    // N_STORES stores per tile.
+    static_assert(NQ % 2 == 0, "the register epilogue regroups pairs of fragment pairs into full 128-B lines");
     const int erow = lane >> 4;
+    const bool lo8 = (lane & 8) == 0;
+    auto ror8 = [](float old, float src, auto mask_tag) {         // lanes of the banks in `mask` take src from the lane 8 away
+        constexpr int MASK = decltype(mask_tag)::value;
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(src), 0x128, 0xf, MASK, false));
+    };
     auto epilogue = [&](int m0e, int n0e) {
         const size_t base = (size_t)m0e * p.cout;
         const long long remain = ((long long)p.M - m0e) * p.cout * 2;
         const int nrec = remain > 0x7fffffffLL ? 0x7fffffff : (int)remain;      // rows >= M are out of range
         const __amdgpu_buffer_rsrc_t y_hi_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_hi + base), 0, nrec, 0x00020000);
         const __amdgpu_buffer_rsrc_t y_lo_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_lo + base), 0, nrec, 0x00020000);
-        int off[NQ][PF];
         f4 sc[NQ][2], sh[NQ][2];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int col = wr * (TC / C::NWR) + (2 * q + (erow & 1)) * 16 + (erow >> 1) * 8;     // cout within the tile
-            const int co = n0e + col;
-            const int dead = (p.cout - 1 - co) & (int)OOB;                                       // co >= cout: nothing to store
+        for (int q = 0; q < NQ; ++q) {              // scale / shift in the accumulator layout
+            const int co = n0e + wr * (TC / C::NWR) + (2 * q + (erow & 1)) * 16 + (erow >> 1) * 8;
             sc[q][0] = *(const f4*)(p.scale + co);          // scale/shift are padded to cout_pad >= n_tiles_c * TC
             sc[q][1] = *(const f4*)(p.scale + co + 4);
             sh[q][0] = *(const f4*)(p.shift + co);
             sh[q][1] = *(const f4*)(p.shift + co + 4);
+        }
+        int offA[NQ / 2][PF];                       // byte offset of this lane's 16 B in instruction A; B is 8 pixel rows further
+        const int row8 = 8 * p.cout * 2;
+#pragma unroll
+        for (int t = 0; t < NQ / 2; ++t) {
+            const int qsel = 2 * t + (lo8 ? 0 : 1);
+            const int co = n0e + wr * (TC / C::NWR) + (2 * qsel + (erow & 1)) * 16 + (erow >> 1) * 8;
+            const int dead = (p.cout - 1 - co) & (int)OOB;                     // co >= cout: nothing to store
 #pragma unroll
             for (int b = 0; b < PF; ++b) {
-                const int pl = wc * (TP / C::NWC) + b * 16 + lrow;
-                off[q][b] = (pl * p.cout + co) * 2 | dead;
+                const int pl = wc * (TP / C::NWC) + b * 16 + (lane & 7);
+                offA[t][b] = (pl * p.cout + co) * 2 | dead;
             }
         }
-        u4 rh[NQ][PF], rl[NQ][PF];
+        u4 rh[NQ / 2][PF][2], rl[NQ / 2][PF][2];
         if (p.r_hi) {
             const __amdgpu_buffer_rsrc_t r_hi_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.r_hi + base), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_lo_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.r_lo + base), 0, nrec, 0x00020000);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+            for (int t = 0; t < NQ / 2; ++t)
 #pragma unroll
-                for (int b = 0; b < PF; ++b) {
-                    if (p.dbg & 1) {
-                        rh[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, off[q][b], 0, 2);      // nt: streamed once
-                        rl[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, off[q][b], 0, 2);
-                    } else {
-                        rh[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, off[q][b], 0, 0);
-                        rl[q][b] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, off[q][b], 0, 0);
+                for (int b = 0; b < PF; ++b)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        rh[t][b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, offA[t][b] + k * row8, 0, 2);      // nt: streamed once
+                        rl[t][b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, offA[t][b] + k * row8, 0, 2);
                     }
-                }
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int t = 0; t < NQ / 2; ++t) {
 #pragma unroll
             for (int b = 0; b < PF; ++b) {
-                float v[8];
+                float ve[8], vo[8];                 // pairs qe = 2t, qo = 2t+1 in the accumulator layout, BatchNorm applied
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // (copy the vector elements into scalars first: __builtin_bit_cast applied to an ext_vector element
                     // lvalue reads element 0 whatever the subscript -- clang 22 / ROCm 7.2)
-                    const float ea = acc[2 * q][b][j], eb = acc[2 * q + 1][b][j];
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(ea), __float_as_uint(eb), false, false);
-                    v[j] = __uint_as_float((unsigned)sw[0]) * sc[q][0][j] + sh[q][0][j];
-                    v[4 + j] = __uint_as_float((unsigned)sw[1]) * sc[q][1][j] + sh[q][1][j];
+                    const float e0 = acc[4 * t][b][j], e1 = acc[4 * t + 1][b][j], o0 = acc[4 * t + 2][b][j], o1 = acc[4 * t + 3][b][j];
+                    const auto se = __builtin_amdgcn_permlane16_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+                    const auto so = __builtin_amdgcn_permlane16_swap(__float_as_uint(o0), __float_as_uint(o1), false, false);
+                    ve[j] = __uint_as_float((unsigned)se[0]) * sc[2 * t][0][j] + sh[2 * t][0][j];
+                    ve[4 + j] = __uint_as_float((unsigned)se[1]) * sc[2 * t][1][j] + sh[2 * t][1][j];
+                    vo[j] = __uint_as_float((unsigned)so[0]) * sc[2 * t + 1][0][j] + sh[2 * t + 1][0][j];
+                    vo[4 + j] = __uint_as_float((unsigned)so[1]) * sc[2 * t + 1][1][j] + sh[2 * t + 1][1][j];
                 }
-                if (p.r_hi) {
-                    const u4 ra = rh[q][b], rc = rl[q][b];
-                    const h8 a = __builtin_bit_cast(h8, ra);
-                    const h8 c = __builtin_bit_cast(h8, rc);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)a[j] + (float)c[j];
-                }
-                if (p.relu) {
+                for (int k = 0; k < 2; ++k) {       // k = 0: instruction A (pixels 0-7 of the fragment), 1: B (pixels 8-15)
+                    float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                h8 oh, ol;
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = k == 0 ? ror8(ve[j], vo[j], std::integral_constant<int, 0xC>{})      // lanes 8-15 <- qo of the pixel 8 below
+                                      : ror8(vo[j], ve[j], std::integral_constant<int, 0x3>{});     // lanes 0-7 <- qe of the pixel 8 above
+                    if (p.r_hi) {
+                        const u4 ra = rh[t][b][k], rc = rl[t][b][k];
+                        const h8 a = __builtin_bit_cast(h8, ra);
+                        const h8 c = __builtin_bit_cast(h8, rc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    half_t hi, lo;
-                    split_f32(v[j], hi, lo);
-                    oh[j] = hi;
-                    ol[j] = lo;
-                }
-                if (p.dbg & 2) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, off[q][b], 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, off[q][b], 0, 2);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, off[q][b], 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, off[q][b], 0, 0);
+                        for (int j = 0; j < 8; ++j) v[j] += (float)a[j] + (float)c[j];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    h8 oh, ol;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        half_t hi, lo;
+                        split_f32(v[j], hi, lo);
+                        oh[j] = hi;
+                        ol[j] = lo;
+                    }
+                    if (p.dbg & 2) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[t][b] + k * row8, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[t][b] + k * row8, 0, 2);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[t][b] + k * row8, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[t][b] + k * row8, 0, 0);
+                    }
                 }
             }
         }

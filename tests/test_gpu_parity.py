@@ -195,27 +195,27 @@ def test_conv_layers_resnet101(eng101, name):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 8])
 @pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv3", "layer2.0.conv2", "layer3.5.conv2", "layer4.2.conv3"])
 def test_conv_every_tile_variant(eng101, name, tile):
     """Each kernel variant (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""
     if tile >= 8 and name == "layer1.0.conv1":
-        assert eng101._lib.mpx_set_conv_tile(eng101._h, _layer_index(eng101, name), tile) == -1     # persistent tiles: cout >= 128
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, _layer_index(eng101, name), tile) == -1     # persistent tile: cout >= 128
         return
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [8, 9])
+@pytest.mark.parametrize("tile", [8])
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 161), ("layer3.5.conv1", 201), ("layer2.1.conv3", 25), ("layer1.1.conv3", 25),
                                         ("layer4.1.conv1", 401), ("layer3.0.conv2", 201)])
 def test_conv_persistent_kernel_many_tiles(eng101, name, tile, batch):
-    """The persistent kernels (csrc/mpx_convp.h) with MORE tiles than the 512 resident workgroups (600 .. 2000 tiles,
+    """The persistent kernel (csrc/mpx_convp.h) with MORE tiles than the 512 resident workgroups (600 .. 2000 tiles,
     ragged last tile), so that workgroups walk several tiles: next-tile prologue under the epilogue, ring hand-over,
     counted waits across tiles.  (mpx_conv_bn_act takes caller planes, so the batch is not bound by the engine's.)"""
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [-1, 2, 7, 8, 9])
+@pytest.mark.parametrize("tile", [-1, 2, 7, 8])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):
     """mpx_conv_dual_bn_act: layerN.0.conv3 + layerN.0.downsample K-concatenated in one launch (the default path of
@@ -775,7 +775,8 @@ def test_small_network_ops(mpx_lib, dev, golden_dir):
         _lib.check(eng._h, eng._lib.mpx_avgpool2_pad(eng._h, _p(xh), _p(xl), _p(oh), _p(ol), 3, 16, 32, 32, eng._stream()), "avgpool2_pad")
         torch.cuda.synchronize()
         want = F.avg_pool2d(merge(xh, xl).cpu().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
-        assert torch.equal(merge(oh, ol).cpu(), want)
+        got = merge(oh, ol).cpu()          # the fp32 average, stored as hi + lo (22 bits)
+        assert (got - want).abs().max().item() <= 2.0 ** -21 * want.abs().max().item() and torch.equal(got[..., 16:], torch.zeros(3, 8, 8, 16))
         assert eng._lib.mpx_avgpool2_pad(eng._h, _p(xh), _p(xl), _p(oh), _p(ol), 3, 15, 32, 32, None) == -1
         p = "pic0/"
         seg = g[p + "segments"]
