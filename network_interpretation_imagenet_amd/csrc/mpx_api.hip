@@ -4,6 +4,7 @@
 #include "mpx_kernels.h"
 #include "mpx_conv3p.h"
 #include "mpx_convp.h"
+#include "mpx_conv256.h"
 
 #include <algorithm>
 #include <cmath>
@@ -427,6 +428,23 @@ int launch_convp_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st
     return 0;
 }
 
+// 256x256 tile (mpx_conv256.h, tile id 9): 1x1 stride-1 layers whose cout is a multiple of 256 and whose K is a multiple of 64
+bool conv256_eligible(const ConvLayer& L) {
+    return !L.is_fc && !L.is_stem && L.d.ksize == 1 && L.d.stride == 1 && L.d.pad == 0 && L.cout_store % 256 == 0 &&
+           L.cin_pad % 64 == 0 && L.cin_pad == L.d.cin;
+}
+
+int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = p.cout / Conv256::TC;
+    if (p.n_tiles_c * Conv256::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const int n_tiles_p = (p.M + Conv256::TP - 1) / Conv256::TP;
+    const long long nblocks = (long long)n_tiles_p * p.n_tiles_c;
+    if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    hipLaunchKernelGGL(conv256_f16x3_kernel, dim3((unsigned)nblocks), dim3(Conv256::NT), Conv256::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Rows of the largest input patch any TP-pixel tile of an HxH map needs (mpx_conv3p.h), rounded up to 16.
 int patch_rows_needed(int H, int TP) {
     const int W = H, PW = W + 2, PIMG = (H + 2) * PW, howo = H * W;
@@ -517,6 +535,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
     switch (L.tile) {
+        case 9: return launch_conv256(h, p, L.d.cout_pad, st);
         case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
@@ -759,6 +778,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv256_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
@@ -835,7 +856,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 8) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 9) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile == 9 && !conv256_eligible(L))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the 256x256 kernel (9) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0 (%s is not one)", L.d.name);
     if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
     if (tile == 6 && !patch_eligible(L.d))

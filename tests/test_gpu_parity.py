@@ -215,6 +215,19 @@ def test_conv_persistent_kernel_many_tiles(eng101, name, tile, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=tile)
 
 
+@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
+                                        ("layer1.1.conv3", 2), ("layer4.1.conv1", 21), ("layer4.2.conv3", 9), ("layer1.1.conv1", 1)])
+def test_conv256_kernel(eng101, name, batch):
+    """Tile id 9 = the 256x256-tile kernel for 1x1 stride-1 layers (csrc/mpx_conv256.h): quadrant-snaked K step on a
+    two-stage 128-KB ring; ragged pixel counts (last tile partial), K from 64 (one loop iteration) to 2048, with and without
+    residual.  layer1.1.conv1 (cout 64) is not eligible."""
+    i = _layer_index(eng101, name)
+    if eng101.layers[i].cout % 256:
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 9) == -1
+        return
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=9)
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 7, 8])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):

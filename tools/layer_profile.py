@@ -44,7 +44,10 @@ if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with clas
         else:
             cls = "k1exp" if d.cout > d.cin else "k1red"
         if cls in rules and d.name != b"fc":
-            eng.set_conv_tile(i, int(rules[cls]))
+            try:
+                eng.set_conv_tile(i, int(rules[cls]))
+            except Exception:           # the layer is not eligible for that kernel: keep its default
+                pass
 if os.environ.get("MPX_TILE_1X1"):      # tool-only override: one tile variant on every 1x1 conv with cout >= 128
     for i, d in enumerate(eng.layers):
         if d.ksize == 1 and d.cout >= 128:
