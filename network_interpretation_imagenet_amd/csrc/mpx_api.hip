@@ -497,7 +497,12 @@ int default_tile(const mpx_conv_desc& d) {
     if (d.ksize == 3) return 0;
     // expanding 1x1 layers (short K, long epilogue): four waves per SIMD cover the epilogue better, -2..4 % in the
     // network; the reducing ones (long K) gain nothing from it
-    return (d.stride == 1 && d.cout > d.cin) ? 7 : 2;
+    if (d.stride == 1 && d.cout > d.cin) return 7;
+    // reducing / square 1x1 stride-1 layers with cout % 256 == 0: the 256x256 tile (mpx_conv256.h) halves the operand bytes
+    // per MAC and runs +10..18 % (1024->256: 365 vs 322 TFLOP/s, 1024->512: 411 vs 346); expanding layers lose on it (one
+    // workgroup per CU: nothing covers the long epilogue)
+    if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout % 256 == 0 && d.cin % 64 == 0) return 9;
+    return 2;
 }
 
 int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
@@ -534,8 +539,31 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
         if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
+    if (L.tile == 9) {
+        // One 256x256 tile per CU at a time: a launch is whole "rounds" of num_cus tiles plus a remainder that would keep
+        // most CUs idle for a full tile time (14x14 maps at batch 2048: 1568 tiles = 6.125 rounds).  When the remainder is
+        // small, the whole rounds go to the 256x256 kernel and the last pixels (1x1 stride 1: rows are independent, so a
+        // pixel range is a pointer offset) to the 128x128 kernel, whose tiles are a quarter of the size.
+        const long long tiles_c = p.cout / Conv256::TC;
+        const long long tiles_p = (M + Conv256::TP - 1) / Conv256::TP;
+        const long long total = tiles_p * tiles_c, rounds = total / h->num_cus, rest = total - rounds * h->num_cus;
+        if (rounds >= 1 && rest > 0 && 2 * rest <= h->num_cus && h->num_cus % tiles_c == 0) {
+            const long long m_a = rounds * h->num_cus / tiles_c * Conv256::TP;          // pixels of the whole rounds
+            ConvParams q = p;
+            p.M = (int)m_a;
+            int rc = launch_conv256(h, p, L.d.cout_pad, st);
+            if (rc) return rc;
+            q.M = (int)(M - m_a);
+            q.x_hi += (size_t)m_a * L.cin_pad; q.x_lo += (size_t)m_a * L.cin_pad;
+            q.y_hi += (size_t)m_a * p.cout; q.y_lo += (size_t)m_a * p.cout;
+            if (q.r_hi) { q.r_hi += (size_t)m_a * p.cout; q.r_lo += (size_t)m_a * p.cout; }
+            // (hin/win only enter the 1x1 kernel through the per-image offsets: treat the rest as one image row of pixels)
+            q.hin = 1; q.win = q.M; q.ho = 1; q.wo = q.M;
+            return launch_conv_tile<ConvTile2>(h, q, L.d.cout_pad, st);
+        }
+        return launch_conv256(h, p, L.d.cout_pad, st);
+    }
     switch (L.tile) {
-        case 9: return launch_conv256(h, p, L.d.cout_pad, st);
         case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);

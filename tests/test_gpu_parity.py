@@ -216,11 +216,13 @@ def test_conv_persistent_kernel_many_tiles(eng101, name, tile, batch):
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
-                                        ("layer1.1.conv3", 2), ("layer4.1.conv1", 21), ("layer4.2.conv3", 9), ("layer1.1.conv1", 1)])
+                                        ("layer1.1.conv3", 2), ("layer4.1.conv1", 21), ("layer4.2.conv3", 9), ("layer1.1.conv1", 1),
+                                        ("layer3.5.conv1", 340), ("layer4.1.conv1", 700)])      # whole rounds + small remainder: split launch
 def test_conv256_kernel(eng101, name, batch):
     """Tile id 9 = the 256x256-tile kernel for 1x1 stride-1 layers (csrc/mpx_conv256.h): quadrant-snaked K step on a
     two-stage 128-KB ring; ragged pixel counts (last tile partial), K from 64 (one loop iteration) to 2048, with and without
-    residual.  layer1.1.conv1 (cout 64) is not eligible."""
+    residual.  layer1.1.conv1 (cout 64) is not eligible.  The two large batches give 261 / 268 tiles on 256 CUs: the
+    engine then runs the 256 whole-round tiles on this kernel and the remaining pixels on the 128x128 kernel."""
     i = _layer_index(eng101, name)
     if eng101.layers[i].cout % 256:
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 9) == -1
