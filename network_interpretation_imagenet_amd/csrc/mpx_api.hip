@@ -97,7 +97,6 @@ struct mpx_engine {
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
     bool in_forward = false;
-    int dbg = 0;
     bool fuse_ds = true;    // mpx_forward runs a block's last conv and its downsample conv as one launch (mpx_set_fusion)
     bool prof_on = false;
     std::vector<ProfRec> prof_pool;
@@ -419,7 +418,6 @@ int launch_convp_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st
     if (DUAL && (((p.k1 >> 5) - Cfg::NSX) < 0 || (((p.k1 >> 5) - Cfg::NSX) & 1)))
         return fail(h, MPX_E_INTERNAL, "dual conv: k1/32 - ring depth must be even and >= 0");
     p.n_tiles = (int)n_tiles;
-    p.dbg = h->dbg;
     const int wg_per_cu = (160 * 1024) / Cfg::RING < Cfg::MINB * 256 / Cfg::NT ? (160 * 1024) / Cfg::RING : Cfg::MINB * 256 / Cfg::NT;
     const long long resident = (long long)h->num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);     // a multiple of 8 (256 CUs)
     const unsigned grid = (unsigned)(n_tiles < resident ? n_tiles : resident);
@@ -730,7 +728,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (rc) { delete h; return rc; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { delete h; return (int)e; }
-    if (const char* dbg = std::getenv("MPX_DBG")) h->dbg = std::atoi(dbg);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;

@@ -69,7 +69,6 @@ struct ConvParams {
     const half_t* x2_lo;
     int hin2, win2, pix_stride2, stride2;
     int k1;
-    int dbg;                 // experiment switches (MPX_DBG environment variable at mpx_create; 0 in production)
     int n_tiles;             // persistent kernels (mpx_convp.h): n_tiles_p * n_tiles_c, walked by a fixed grid
 #ifdef MPX_DIAG
     unsigned long long* stamps;   // diagnostic build only (tools/probes/conv_timeline.py): 8 u64 per workgroup
@@ -494,5 +493,7 @@ constexpr int CONV_NUM_TILES = 6;                  // ids 0..5; 6 = the 3x3 patc
 // SIMD).  Each wave issues half the LDS-DMA pieces and half the MFMAs of a tile-2 wave; with four waves per SIMD one
 // wave's DMA issue and barrier waits are covered by three others.
 typedef ConvCfg<128, 128, 4, 2, 2, 2, 4> ConvTile7;
+// (tile 7 with a 3-deep X ring, 80 KB, was measured in round 2: two workgroups still co-reside and the K loop's share of a
+// workgroup's life falls from 47 % to 40 %, but the layer time does not move: DESIGN.md 5)
 
 }  // namespace mpx

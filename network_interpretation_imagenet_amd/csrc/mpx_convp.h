@@ -323,13 +323,8 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
                         oh[j] = hi;
                         ol[j] = lo;
                     }
-                    if (p.dbg & 2) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[t][b] + k * row8, 0, 2);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[t][b] + k * row8, 0, 2);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[t][b] + k * row8, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[t][b] + k * row8, 0, 0);
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[t][b] + k * row8, 0, 2);    // nt
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[t][b] + k * row8, 0, 2);
                 }
             }
         }
