@@ -503,6 +503,25 @@ int default_tile(const mpx_conv_desc& d) {
     return 2;
 }
 
+// one launch of layer L's conv with the given kernel variant
+int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hipStream_t st) {
+    if (tile == 6) {
+        if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
+        return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
+    }
+    switch (tile) {
+        case 9: return launch_conv256(h, p, L.d.cout_pad, st);
+        case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
+        case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
+        case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
+        case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
+        case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+        case 7: return launch_conv_tile<ConvTile7>(h, p, L.d.cout_pad, st);
+        case 4: return launch_conv_tile<ConvTile4>(h, p, L.d.cout_pad, st);
+        default: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
+    }
+}
+
 int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, const half_t* r_hi,
                 const half_t* r_lo, half_t* y_hi, half_t* y_lo, float* y_f32, int B, hipStream_t st) {
     const ConvLayer& L = h->convs[i];
@@ -533,44 +552,36 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     p.stamps = h->stamps;
 #endif
     ProfScope ps(h, st, OP_CONV, i);
-    if (L.tile == 6) {
-        if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
-        return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
+    // Kernels that keep ONE workgroup per CU (tiles 0, 6, 9) run in "rounds" of num_cus tiles; a small remainder would
+    // keep most CUs idle for a whole tile time (14x14 maps at batch 2048: 1568 tiles of 256x256 = 6.125 rounds; the 3x3
+    // patch kernel: 12.25 rounds).  Then the images of the whole rounds go to that kernel and the last few images (images
+    // are independent: an image range is a pointer offset) to the 128x128 kernel, whose tiles are a quarter of the size.
+    int big_tc = 0, big_tp = 0;
+    if (L.tile == 9) { big_tc = Conv256::TC; big_tp = Conv256::TP; }
+    else if (L.tile == 0) { big_tc = ConvTile0::TC; big_tp = ConvTile0::TP; }
+    else if (L.tile == 6 && L.d.cout > 64) {
+        big_tc = PatchTile0::TC;
+        big_tp = patch_fits<PatchTile0>(L.d) ? PatchTile0::TP : PatchTile2::TP;
     }
-    if (L.tile == 9) {
-        // One 256x256 tile per CU at a time: a launch is whole "rounds" of num_cus tiles plus a remainder that would keep
-        // most CUs idle for a full tile time (14x14 maps at batch 2048: 1568 tiles = 6.125 rounds).  When the remainder is
-        // small, the whole rounds go to the 256x256 kernel and the last pixels (1x1 stride 1: rows are independent, so a
-        // pixel range is a pointer offset) to the 128x128 kernel, whose tiles are a quarter of the size.
-        const long long tiles_c = p.cout / Conv256::TC;
-        const long long tiles_p = (M + Conv256::TP - 1) / Conv256::TP;
+    if (big_tc && !L.is_stem) {
+        const long long tiles_c = (p.cout + big_tc - 1) / big_tc, tiles_p = (M + big_tp - 1) / big_tp;
         const long long total = tiles_p * tiles_c, rounds = total / h->num_cus, rest = total - rounds * h->num_cus;
-        if (rounds >= 1 && rest > 0 && 2 * rest <= h->num_cus && h->num_cus % tiles_c == 0) {
-            const long long m_a = rounds * h->num_cus / tiles_c * Conv256::TP;          // pixels of the whole rounds
+        const long long howo = (long long)p.ho * p.wo;
+        const long long n_a = rounds * h->num_cus / tiles_c * big_tp / howo;           // images that fill the whole rounds
+        if (rounds >= 1 && rest > 0 && 2 * rest <= h->num_cus && n_a >= 1 && n_a < B) {
             ConvParams q = p;
-            p.M = (int)m_a;
-            int rc = launch_conv256(h, p, L.d.cout_pad, st);
+            p.M = (int)(n_a * howo);
+            int rc = dispatch_conv(h, L, p, L.tile, st);
             if (rc) return rc;
-            q.M = (int)(M - m_a);
-            q.x_hi += (size_t)m_a * L.cin_pad; q.x_lo += (size_t)m_a * L.cin_pad;
-            q.y_hi += (size_t)m_a * p.cout; q.y_lo += (size_t)m_a * p.cout;
-            if (q.r_hi) { q.r_hi += (size_t)m_a * p.cout; q.r_lo += (size_t)m_a * p.cout; }
-            // (hin/win only enter the 1x1 kernel through the per-image offsets: treat the rest as one image row of pixels)
-            q.hin = 1; q.win = q.M; q.ho = 1; q.wo = q.M;
-            return launch_conv_tile<ConvTile2>(h, q, L.d.cout_pad, st);
+            const size_t xo = (size_t)n_a * p.hin * p.win * p.pix_stride, yo = (size_t)n_a * howo * p.cout;
+            q.M = (int)(M - n_a * howo);
+            q.x_hi += xo; q.x_lo += xo;
+            q.y_hi += yo; q.y_lo += yo;
+            if (q.r_hi) { q.r_hi += yo; q.r_lo += yo; }
+            return dispatch_conv(h, L, q, 2, st);
         }
-        return launch_conv256(h, p, L.d.cout_pad, st);
     }
-    switch (L.tile) {
-        case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
-        case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
-        case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
-        case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
-        case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
-        case 7: return launch_conv_tile<ConvTile7>(h, p, L.d.cout_pad, st);
-        case 4: return launch_conv_tile<ConvTile4>(h, p, L.d.cout_pad, st);
-        default: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
-    }
+    return dispatch_conv(h, L, p, L.tile, st);
 }
 
 // A block's last 1x1 conv with its downsample branch K-concatenated: out = relu(s * (W3' . t2 + Wds' . x) + shift)
