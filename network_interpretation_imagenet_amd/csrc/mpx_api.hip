@@ -392,7 +392,7 @@ struct ProfScope {
     }
 };
 
-template <class Cfg, bool DUAL = false, bool CHUNK_MAJOR = false>
+template <class Cfg, bool DUAL = false>
 int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;     // weights are padded to cout_pad >= n_tiles_c * TC rows
     if (p.n_tiles_c * Cfg::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
@@ -401,7 +401,7 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
     if (DUAL && (((p.k1 >> 5) - Cfg::NSX) < 0 || (((p.k1 >> 5) - Cfg::NSX) & 1)))
         return fail(h, MPX_E_INTERNAL, "dual conv: k1/32 - ring depth must be even and >= 0");
-    hipLaunchKernelGGL((conv_f16x3_kernel<Cfg, DUAL, CHUNK_MAJOR>), dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
+    hipLaunchKernelGGL((conv_f16x3_kernel<Cfg, DUAL>), dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
@@ -578,9 +578,6 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
             q.x_hi += xo; q.x_lo += xo;
             q.y_hi += yo; q.y_lo += yo;
             if (q.r_hi) { q.r_hi += yo; q.r_lo += yo; }
-            // same summation order as the big-tile kernel, so a mask's score does not depend on where in the batch it sits:
-            // tiles 0 and 9 sum like tile 2; the patch kernel (6) sums chunk-major
-            if (L.tile == 6) return launch_conv_tile<ConvTile2, false, true>(h, q, L.d.cout_pad, st);
             return dispatch_conv(h, L, q, 2, st);
         }
     }
@@ -810,8 +807,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
     if (e == hipSuccess)

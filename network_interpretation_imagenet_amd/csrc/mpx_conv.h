@@ -127,10 +127,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-// CHUNK_MAJOR: the K loop runs (32-channel chunk, then the taps) like mpx_conv3p.h instead of (tap, then the channels), so
-// that this kernel sums in the patch kernel's order and gives the same bits (used for the few images the engine splits off
-// the patch kernel's last round; needs NSW == NSX).
-template <class C, bool DUAL = false, bool CHUNK_MAJOR = false>
+template <class C, bool DUAL = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,11 +220,9 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
 
     // `live` = false (a step past the end of K) keeps the ring and the vmcnt bookkeeping in shape: the X pieces
     // read out of range (zeros), the W pieces read whatever follows the row (never used).
-    int ky = 0, kx = 0, c0 = 0;     // coordinates of the NEXT step to stage
     auto stage_w = [&](int buf, int ks) {
         char* sb = smem + buf * WSTAGE;
-        static_assert(!CHUNK_MAJOR || C::NSW == C::NSX, "chunk-major order: W and X stages of a step share their coordinates");
-        const int soff = CHUNK_MAJOR ? ((ky * p.kw + kx) * p.k_per_tap + c0) * 2 : ks * 64;
+        const int soff = ks * 64;
         // a step past the end of K only keeps the vmcnt bookkeeping in shape: an out-of-range offset makes the
         // buffer unit return zeros without a memory access, so the drain in front of the epilogue is short
         const int dead = ks < nk ? 0 : (int)OOB;
@@ -271,25 +266,16 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
 #pragma unroll
         for (int b = 0; b < PF; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
+    int ky = 0, kx = 0, c0 = 0;     // coordinates of the NEXT step to stage
     int cb = 0;                     // DUAL: channel offset of the next stage within the second operand
     auto advance = [&]() {      // branch-free (the K step must stay one basic block for the scheduler)
-        if (CHUNK_MAJOR) {      // taps fastest, then the next 32 channels
-            kx += 1;
-            const bool wkx = (kx == p.kw);
-            kx = wkx ? 0 : kx;
-            ky += wkx ? 1 : 0;
-            const bool wky = (ky == p.kh);
-            ky = wky ? 0 : ky;
-            c0 += wky ? 32 : 0;
-        } else {
-            c0 += 32;
-            const bool wc0 = (c0 == p.k_per_tap);
-            c0 = wc0 ? 0 : c0;
-            kx += wc0 ? 1 : 0;
-            const bool wkx = (kx == p.kw);
-            kx = wkx ? 0 : kx;
-            ky += wkx ? 1 : 0;
-        }
+        c0 += 32;
+        const bool wc0 = (c0 == p.k_per_tap);
+        c0 = wc0 ? 0 : c0;
+        kx += wc0 ? 1 : 0;
+        const bool wkx = (kx == p.kw);
+        kx = wkx ? 0 : kx;
+        ky += wkx ? 1 : 0;
     };
 
     const int lrow = lane & 15;
