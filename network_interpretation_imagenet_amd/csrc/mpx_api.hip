@@ -552,17 +552,15 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     p.stamps = h->stamps;
 #endif
     ProfScope ps(h, st, OP_CONV, i);
-    // Kernels that keep ONE workgroup per CU (tiles 0, 6, 9) run in "rounds" of num_cus tiles; a small remainder would
-    // keep most CUs idle for a whole tile time (14x14 maps at batch 2048: 1568 tiles of 256x256 = 6.125 rounds; the 3x3
-    // patch kernel: 12.25 rounds).  Then the images of the whole rounds go to that kernel and the last few images (images
-    // are independent: an image range is a pointer offset) to the 128x128 kernel, whose tiles are a quarter of the size.
+    // The 256x256 kernel keeps ONE workgroup per CU, so a launch runs in "rounds" of num_cus tiles and a small remainder would
+    // keep most CUs idle for a whole tile time (14x14 maps at batch 2048: 1568 tiles = 6.125 rounds).  Then the images of
+    // the whole rounds go to that kernel and the last few images (images are independent: an image range is a pointer
+    // offset) to the 128x128 kernel, whose tiles are a quarter of the size and which sums in the same order (bit-identical
+    // scores wherever a mask sits in the batch): 1024->256 12.9 -> 12.3 ms, 2048->512 1.15 -> 1.01 ms per batch.  (The same
+    // split of the 3x3 patch kernel's and tile 0's last round was measured and gains nothing: their remainder lives as long
+    // as one of their tiles whatever its tile size)
     int big_tc = 0, big_tp = 0;
     if (L.tile == 9) { big_tc = Conv256::TC; big_tp = Conv256::TP; }
-    else if (L.tile == 0) { big_tc = ConvTile0::TC; big_tp = ConvTile0::TP; }
-    else if (L.tile == 6 && L.d.cout > 64) {
-        big_tc = PatchTile0::TC;
-        big_tp = patch_fits<PatchTile0>(L.d) ? PatchTile0::TP : PatchTile2::TP;
-    }
     if (big_tc && !L.is_stem) {
         const long long tiles_c = (p.cout + big_tc - 1) / big_tc, tiles_p = (M + big_tp - 1) / big_tp;
         const long long total = tiles_p * tiles_c, rounds = total / h->num_cus, rest = total - rounds * h->num_cus;

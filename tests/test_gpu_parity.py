@@ -230,14 +230,6 @@ def test_conv256_kernel(eng101, name, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=9)
 
 
-@pytest.mark.parametrize("name,tile,batch", [("layer3.5.conv2", 6, 170), ("layer3.0.conv2", 0, 170), ("layer4.1.conv2", 6, 300)])
-def test_conv_round_split_of_one_workgroup_per_cu_kernels(eng101, name, tile, batch):
-    """Kernels with one workgroup per CU (tiles 0, 6, 9) hand a small last round to the 128x128 kernel: batch sizes that give
-    one whole round of 256 tiles plus a few (262 / 262 / 308 tiles): the images of the whole round run on the big-tile kernel,
-    the last images on tile 2, split at an image boundary (3x3 layers need their neighbours)."""
-    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=tile)
-
-
 @pytest.mark.parametrize("tile", [-1, 2, 7, 8])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):
