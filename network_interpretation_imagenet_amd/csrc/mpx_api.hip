@@ -5,6 +5,7 @@
 #include "mpx_conv3p.h"
 #include "mpx_convp.h"
 #include "mpx_conv256.h"
+#include "mpx_convx.h"
 
 #include <algorithm>
 #include <cmath>
@@ -432,6 +433,26 @@ bool conv256_eligible(const ConvLayer& L) {
            L.cin_pad % 64 == 0 && L.cin_pad == L.d.cin;
 }
 
+// persistent expanding-1x1 kernel (mpx_convx.h, tile id 10): as tile 9 plus K >= 128; needs at least one tile per CU
+bool convx_eligible(const ConvLayer& L) { return conv256_eligible(L) && L.cin_pad >= 128; }
+
+int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = p.cout / ConvX::TC;
+    if (p.n_tiles_c * ConvX::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const long long n_tiles_p = ((long long)p.M + ConvX::TP - 1) / ConvX::TP;
+    const long long total = n_tiles_p * p.n_tiles_c;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    // one workgroup per CU; the grid must be a multiple of 8 (XCD classes) and of n_tiles_c (a workgroup keeps its cout tile)
+    long long grid = h->num_cus;
+    if (total < grid) grid = total;
+    const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
+    grid = grid / unit * unit;
+    if (grid <= 0) return fail(h, MPX_E_ARG, "convx: too few tiles for a persistent grid");
+    hipLaunchKernelGGL(convx_f16x3_kernel, dim3((unsigned)grid), dim3(ConvX::NT), ConvX::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = p.cout / Conv256::TC;
     if (p.n_tiles_c * Conv256::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
@@ -510,6 +531,7 @@ int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hi
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
     switch (tile) {
+        case 10: return launch_convx(h, p, L.d.cout_pad, st);
         case 9: return launch_conv256(h, p, L.d.cout_pad, st);
         case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
@@ -814,6 +836,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv256_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
@@ -890,7 +914,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 9) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 10) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile == 10 && !convx_eligible(L))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent expanding-1x1 kernel (10) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0, cin >= 128 (%s is not one)", L.d.name);
     if (tile == 9 && !conv256_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the 256x256 kernel (9) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0 (%s is not one)", L.d.name);
     if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))

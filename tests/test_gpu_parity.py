@@ -230,6 +230,20 @@ def test_conv256_kernel(eng101, name, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=9)
 
 
+@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv3", 161), ("layer2.1.conv3", 25),
+                                        ("layer4.2.conv3", 200), ("layer3.5.conv1", 201), ("layer4.1.conv1", 9), ("layer1.1.conv3", 2)])
+def test_convx_persistent_expanding_kernel(eng101, name, batch):
+    """Tile id 10 = the persistent pipelined kernel for expanding 1x1 layers (csrc/mpx_convx.h): three-stage ring that runs on
+    across the tiles of a workgroup, register epilogue with residual lines requested two K steps ahead, position-dependent
+    counted vmcnt waits.  Batches give from one tile per workgroup (no tile boundary) up to four (boundaries, ragged last
+    tile), K = 128 (two step pairs) to 2048, with and without residual.  layer1.1.conv3 (K = 64) is not eligible."""
+    i = _layer_index(eng101, name)
+    if eng101.layers[i].cin < 128:
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 10) == -1
+        return
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=10)
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 7, 8])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):
