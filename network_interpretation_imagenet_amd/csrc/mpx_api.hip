@@ -633,7 +633,7 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
     ProfScope ps(h, st, OP_CONV, i);
     if (L.tile == 2) return launch_conv_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
     if (L.tile == 8) return launch_convp_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
-    return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);
+    return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);       // (tiles 7 and 10: the persistent kernel has no dual-operand form)
 }
 
 // Fused planes of a (main, ds) pair from the host copies of both layers.  With s3 = g3/sqrt(v3+eps) and sd likewise,
@@ -1111,7 +1111,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8)) {
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10)) {
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

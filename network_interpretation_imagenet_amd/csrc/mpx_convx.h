@@ -300,7 +300,14 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         rslot = s2;
     };
 
+#ifdef MPX_DIAG
+    const unsigned long long d_start = __builtin_amdgcn_s_memtime();
+    unsigned long long d_k = 0, d_wait = 0, d_epi = 0;
+#endif
     for (int ti = 0; ti < my_tiles; ++ti) {
+#ifdef MPX_DIAG
+        const unsigned long long d_t0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -319,10 +326,32 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         }
         // the epilogue loads were issued behind the DMA of step nk-2; since then only the pieces of step nk-1
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MPX_DIAG
+        const unsigned long long d_t1 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PIECES) : "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MPX_DIAG
+        const unsigned long long d_t2 = __builtin_amdgcn_s_memtime();
+#endif
         epilogue(ti);
+#ifdef MPX_DIAG
+        const unsigned long long d_t3 = __builtin_amdgcn_s_memtime();
+        d_k += d_t1 - d_t0; d_wait += d_t2 - d_t1; d_epi += d_t3 - d_t2;
+#endif
     }
+#ifdef MPX_DIAG
+    // per workgroup: SUMS over its tiles, laid out so that tools/probes/conv_timeline.py prints them as its phases:
+    // "prologue" = K loops, "k-loop" = waits for the residual lines, "epilogue-1" = epilogue arithmetic + store issue
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned long long* o_ = p.stamps + (size_t)blockIdx.x * 8;
+        o_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        o_[1] = d_start; o_[2] = d_start + d_k; o_[3] = d_start + d_k + d_wait; o_[4] = d_start + d_k + d_wait + d_epi;
+        o_[5] = __builtin_amdgcn_s_memtime();
+        o_[6] = __builtin_amdgcn_s_memrealtime();
+        o_[7] = (unsigned long long)my_tiles;
+    }
+#endif
     // dead pieces still target this workgroup's LDS: they are older than the last stores
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::EPI_STORES) : "memory");
 #endif

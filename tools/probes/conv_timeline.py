@@ -91,6 +91,9 @@ if __name__ == "__main__":
         lib.mpx_debug_set_stamps(eng._h, None)
         st = stamps.cpu().numpy().reshape(-1, 8)
         st = st[st[:, 5] != 0]
+        if eng.conv_tile(i) == 10:
+            print("   (tile 10 = persistent kernel: per workgroup the SUMS over its %d..%d tiles -- 'prologue' = K loops, 'k-loop' = waits for "
+                  "the residual lines, 'epilogue-1' = epilogue arithmetic and store issue)" % (st[:, 7].min(), st[:, 7].max()))
         n = len(st)
         hw, t_start, t_pro, t_kend, t_epi, t_end, rt_end = (st[:, k].astype(np.int64) for k in range(7))
         span_cyc = t_end.max() - t_start.min()
