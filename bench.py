@@ -50,14 +50,14 @@ def parse():
 
 
 def pmc_traffic(arch, batch):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
-    from inside the process); None unless a profile of this arch and forward batch exists."""
+    """HBM bytes of the conv kernels per forward batch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    cannot be read from inside the process); None unless a profile of this arch and forward batch exists."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         with open(path) as fh:
             j = json.load(fh)
         if j.get("forward_batch") == batch and arch == j.get("arch", "resnet101"):
-            return j["traffic_bytes_per_launch"]
+            return j["write_bytes_per_batch"] + j["fetch_corrected_bytes_per_batch_guide_x2"]       # per forward batch
     return None
 
 
@@ -241,12 +241,16 @@ def main():
         conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
         flops_per_batch = eng.flops_per_forward * batch
         roofline = None
+        traffic_per_batch = pmc_traffic(args.arch, batch)
         if conv_n:
             # dominant kernel = conv_f16x3_kernel (all conv/fc launches).  achieved = algorithmic FLOPs
             # of the launches / their summed HIP-event durations; MFMA-issued FLOPs are 3x algorithmic.
             achieved = flops_per_batch * batches_profiled / (conv_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": pmc_traffic(args.arch, batch),
+                        "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+                        # HBM bytes per conv launch = PMC bytes of the conv kernels per forward batch / conv launches per batch (a
+                        # launch = one layer; 26 of them split their last round off into a second, small kernel dispatch)
+                        "traffic": (traffic_per_batch / (conv_n / batches_profiled)) if traffic_per_batch else None,
                         "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Conv256 C;
+    MPX_STAMP(t_start);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
     for (int w = 0; w < 8; ++w) dma_piece(1, 1, w);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // stage 0 (this wave's pieces); stage 1 stays in flight
     __builtin_amdgcn_s_barrier();
+    MPX_STAMP(t_pro);
 #pragma unroll
     for (int j = 0; j < 8; ++j) read_a(A0, 0, 0, j);
 #pragma unroll
@@ -182,6 +184,8 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
     // the trailing dead DMAs and the last (unused) fragment reads must be over before the ring is reused
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    MPX_STAMP(t_kend);
+    MPX_STAMP(t_epi);
 
     // ---- epilogue: the two cout halves through the ring as an fp32 [256 px][128 cout] tile --------------------------------
     constexpr int RP = 128 * 4;                 // row pitch of the fp32 tile
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
             __builtin_nontemporal_store(ol, (h8*)(p.y_lo + o));
         }
     }
+    MPX_STAMP_WRITE(p, t_start, t_pro, t_kend, t_epi);
 #endif
 }
 

@@ -96,14 +96,15 @@ if __name__ == "__main__":
                   "the residual lines, 'epilogue-1' = epilogue arithmetic and store issue)" % (st[:, 7].min(), st[:, 7].max()))
         n = len(st)
         hw, t_start, t_pro, t_kend, t_epi, t_end, rt_end = (st[:, k].astype(np.int64) for k in range(7))
-        span_cyc = t_end.max() - t_start.min()
-        # clock: memtime cycles per realtime tick (100 MHz) from the latest-ending workgroups of different CUs
-        order = np.argsort(rt_end)
-        lo, hi_ = order[: max(1, n // 50)], order[-max(1, n // 50):]
-        ghz = (t_end[hi_].mean() - t_end[lo].mean()) / max(1.0, (rt_end[hi_].mean() - rt_end[lo].mean())) / 10.0
+        # clock: every CU is busy for (almost) the whole kernel, and s_memtime is consistent within a CU, so the median over the
+        # CUs of (last stamp - first stamp) cycles divided by the kernel's event time is the in-kernel clock
+        key0 = ((hw >> 32) << 16) | ((hw & 0xffffffff) >> 8 & 0xff)
+        spans = np.array([(t_end[key0 == cu].max() - t_start[key0 == cu].min()) for cu in np.unique(key0)], dtype=np.float64)
+        span_cyc = float(np.median(spans))
+        ghz = span_cyc / (ms * 1e6)
         ns = lambda c: c / ghz
-        print("== %s %s B=%d tile=%d: %d->%d k%d res=%d | kernel %.3f ms, %d workgroups, in-kernel clock %.2f GHz, stamped span %.3f ms" % (
-            arch, layer, batch, eng.conv_tile(i), d.cin, d.cout, d.ksize, d.residual, ms, n, ghz, ns(span_cyc) / 1e6))
+        print("== %s %s B=%d tile=%d: %d->%d k%d res=%d | kernel %.3f ms, %d workgroups, in-kernel clock ~%.2f GHz (median CU span / kernel time)" % (
+            arch, layer, batch, eng.conv_tile(i), d.cin, d.cout, d.ksize, d.residual, ms, n, ghz))
         ph = {"prologue": t_pro - t_start, "k-loop": t_kend - t_pro, "epilogue-1 (residual wait, LDS write)": t_epi - t_kend,
               "epilogue-2 (LDS read, add, stores)": t_end - t_epi, "whole workgroup": t_end - t_start}
         for k, v in ph.items():
