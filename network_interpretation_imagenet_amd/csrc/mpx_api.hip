@@ -433,7 +433,8 @@ bool conv256_eligible(const ConvLayer& L) {
            L.cin_pad % 64 == 0 && L.cin_pad == L.d.cin;
 }
 
-// persistent expanding-1x1 kernel (mpx_convx.h, tile id 10): as tile 9 plus K >= 128; needs at least one tile per CU
+// persistent expanding-1x1 kernel (mpx_convx.h, tile id 10): as tile 9 plus K >= 128; a launch with fewer tiles than one grid
+// unit (8 or n_tiles_c workgroups) runs on the 128x128 kernel instead
 bool convx_eligible(const ConvLayer& L) { return conv256_eligible(L) && L.cin_pad >= 128; }
 
 int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
@@ -447,7 +448,7 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (total < grid) grid = total;
     const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
     grid = grid / unit * unit;
-    if (grid <= 0) return fail(h, MPX_E_ARG, "convx: too few tiles for a persistent grid");
+    if (grid <= 0) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);      // fewer tiles than one grid unit: the 128x128 kernel
     hipLaunchKernelGGL(convx_f16x3_kernel, dim3((unsigned)grid), dim3(ConvX::NT), ConvX::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
