@@ -231,12 +231,14 @@ def test_conv256_kernel(eng101, name, batch):
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv3", 161), ("layer2.1.conv3", 25),
-                                        ("layer4.2.conv3", 200), ("layer3.5.conv1", 201), ("layer4.1.conv1", 9), ("layer1.1.conv3", 2)])
+                                        ("layer4.2.conv3", 200), ("layer3.5.conv1", 201), ("layer4.1.conv1", 9), ("layer1.1.conv3", 2),
+                                        ("layer3.5.conv1", 1)])
 def test_convx_persistent_expanding_kernel(eng101, name, batch):
     """Tile id 10 = the persistent pipelined kernel for expanding 1x1 layers (csrc/mpx_convx.h): three-stage ring that runs on
     across the tiles of a workgroup, register epilogue with residual lines requested two K steps ahead, position-dependent
     counted vmcnt waits.  Batches give from one tile per workgroup (no tile boundary) up to four (boundaries, ragged last
-    tile), K = 128 (two step pairs) to 2048, with and without residual.  layer1.1.conv3 (K = 64) is not eligible."""
+    tile), K = 128 (two step pairs) to 2048, with and without residual.  layer1.1.conv3 (K = 64) is not eligible; one image of
+    layer3.5.conv1 is 2 tiles, fewer than a grid unit of 8 workgroups: that launch runs on the 128x128 kernel."""
     i = _layer_index(eng101, name)
     if eng101.layers[i].cin < 128:
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 10) == -1
