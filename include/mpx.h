@@ -99,8 +99,12 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
 int mpx_get_conv_tile(const mpx_engine* h, int i);
 
 /* Host-only packer (no GPU needed; what mpx_set_conv_weights runs before the upload).
- * Produces the fp16 planes w_hi/w_lo [cout_pad][k_packed] (k order = (ky,kx,ci), ci fastest;
- * for the 7x7 stem k = ky*32 + px*4 + c over the NHWC4 padded input), each output channel
+ * Produces the fp16 planes w_hi/w_lo of cout_pad x k_packed elements (k order = (ky,kx,ci), ci fastest;
+ * for the 7x7 stem k = ky*32 + px*4 + c over the NHWC4 padded input) in PIECE-major order: element (row, k) of a plane is at
+ *   ((((row/16) * (k_packed/32) + k/32) * 16 + row%16) * 4 + ((k/8)%4 ^ (((row%16)/8) * 2))) * 8 + k%8
+ * -- [cout_pad/16][k_packed/32][16 rows][four 16-byte chunks, XOR-swizzled by the row], so that each 1-KiB LDS-DMA piece of
+ * the conv kernels is one contiguous run of 8 cache lines already in the order of its LDS image (cout_pad % 16 == 0,
+ * k_packed % 32 == 0).  Each output channel is
  * multiplied by 2^e so that max|w| lies in [512,1024), and the fp32 epilogue
  * scale = gamma/sqrt(var+eps) * 2^-e, shift = beta + (conv_bias - mean)*gamma/sqrt(var+eps).  k_packed = k*k*cin_pad
  * with cin_pad >= cin the channels per pixel of the input planes (padding channels get zero weights).

@@ -667,8 +667,8 @@ int build_fused(mpx_engine* h, int main) {
             const float sv = std::ldexp(row[k], e);
             const half_t vh = (half_t)sv;
             const half_t vl = (half_t)(sv - (float)vh);
-            hi[(size_t)co * K + k] = half_bits(vh);
-            lo[(size_t)co * K + k] = half_bits(vl);
+            hi[w_packed_index(co, k, K)] = half_bits(vh);
+            lo[w_packed_index(co, k, K)] = half_bits(vl);
         }
         sc[co] = (float)std::ldexp(s, -e);
         sh[co] = (float)(((double)L.hbeta[co] - (double)L.hmean[co] * s3) + ((double)D.hbeta[co] - (double)D.hmean[co] * sd));
@@ -696,7 +696,7 @@ int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* c
     if (!d || !w || !w_hi || !w_lo || !scale || !shift) return MPX_E_ARG;
     const int cin = d->cin, cout = d->cout, k = d->ksize, K = d->k_packed;
     const bool stem = (cin == 3 && k == kStemK);
-    if (k <= 0 || cin <= 0 || cout <= 0 || cout > d->cout_pad) return MPX_E_ARG;
+    if (k <= 0 || cin <= 0 || cout <= 0 || cout > d->cout_pad || d->cout_pad % 16 != 0) return MPX_E_ARG;
     // K = k*k*cin_pad: the input planes may carry more channels per pixel than the layer reads (small nets pad to 32)
     const int cin_pad = stem ? 0 : K / (k * k);
     if (stem ? (K != kStemK * 32) : (K != k * k * cin_pad || cin_pad < cin || K % 32 != 0)) return MPX_E_ARG;
@@ -716,14 +716,13 @@ int mpx_pack_conv_weights(const mpx_conv_desc* d, const float* w, const float* c
             std::frexp(mx, &ex);          // mx = f * 2^ex, f in [0.5,1)  ->  mx*2^(10-ex) in [512,1024)
             e = 10 - ex;
         }
-        uint16_t* ph = w_hi + (size_t)co * K;
-        uint16_t* pl = w_lo + (size_t)co * K;
         auto put = [&](int kk, float v) {
             const float sv = std::ldexp(v, e);
             const half_t hi = (half_t)sv;
             const half_t lo = (half_t)(sv - (float)hi);
-            ph[kk] = half_bits(hi);
-            pl[kk] = half_bits(lo);
+            const size_t at = w_packed_index(co, kk, K);
+            w_hi[at] = half_bits(hi);
+            w_lo[at] = half_bits(lo);
         };
         if (stem) {
             for (int ky = 0; ky < k; ++ky)

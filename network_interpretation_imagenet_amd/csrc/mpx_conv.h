@@ -75,6 +75,16 @@ struct ConvParams {
 #endif
 };
 
+// Packed weight planes are PIECE-major: a plane [cout_pad][K] is stored as [cout_pad/16][K/32][16 rows][32 halfs], i.e. every
+// 1-KiB LDS-DMA piece (16 output channels x one 32-wide K step) is contiguous in memory and already in the order of its LDS image
+// (16-B chunk c of row r sits at chunk position c ^ (((r>>3)&1)<<1), the ring's bank swizzle): a lane's source address is
+// piece base + lane*16, a piece is 8 whole 128-B lines instead of 16 half lines scattered over 16 rows (the texture addresser is
+// the busiest unit of the 1x1 kernels).  Element index of weight (row, k) within a plane:
+__host__ __device__ inline size_t w_packed_index(int row, int k, int K) {
+    const int r = row & 15, c = (k >> 3) & 3;
+    return ((((size_t)(row >> 4) * (size_t)(K >> 5) + (size_t)(k >> 5)) * 16 + r) * 4 + (size_t)(c ^ (((r >> 3) & 1) << 1))) * 8 + (size_t)(k & 7);
+}
+
 // Diagnostic build (-DMPX_DIAG, never the product library): wave 0 of every workgroup keeps s_memtime stamps of its
 // phases in SGPRs and writes them, with the CU it ran on, to p.stamps at the end.
 #ifdef MPX_DIAG
@@ -210,19 +220,22 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
             x2_off0[i] = off | ((p.M - 1 - m) & (int)OOB);
         }
     }
-    // W rows of this wave: piece (j*NW + wave) of each plane; HALF_W: one piece of one plane
-    int w_off[WJ];
+    // W pieces of this wave: piece (j*NW + wave) of each plane; HALF_W: one piece of one plane.  The planes are piece-major
+    // (w_packed_index): a lane reads byte lane*16 of the piece, and the piece's position -- (piece * K/32 + ks) KiB -- is
+    // wave-uniform, i.e. the SGPR soffset: no VGPR per piece.
+    const int w_lane = lane * 16;
+    int w_piece[WJ];                 // wave-uniform byte offset of piece j at K step 0
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int piece = C::HALF_W ? (wave % (NW / 2)) : (j * NW + wave);
-        w_off[j] = (piece * 16 + prow) * p.ktot * 2 + src_q * 2;
+        w_piece[j] = piece * 16 * p.ktot * 2;
     }
 
     // `live` = false (a step past the end of K) keeps the ring and the vmcnt bookkeeping in shape: the X pieces
     // read out of range (zeros), the W pieces read whatever follows the row (never used).
     auto stage_w = [&](int buf, int ks) {
         char* sb = smem + buf * WSTAGE;
-        const int soff = ks * 64;
+        const int soff = ks * 1024;
         // a step past the end of K only keeps the vmcnt bookkeeping in shape: an out-of-range offset makes the
         // buffer unit return zeros without a memory access, so the drain in front of the epilogue is short
         const int dead = ks < nk ? 0 : (int)OOB;
@@ -230,13 +243,13 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
         for (int j = 0; j < WJ; ++j) {
             if (C::HALF_W) {
                 if (wave < NW / 2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_lane | dead, soff + w_piece[j], 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_lane | dead, soff + w_piece[j], 0, 0);
             } else {
                 const int d = (j * NW + wave) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j] | dead, soff, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j] | dead, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_lane | dead, soff + w_piece[j], 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_lane | dead, soff + w_piece[j], 0, 0);
             }
         }
     };

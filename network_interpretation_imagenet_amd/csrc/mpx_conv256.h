@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
     // this wave moves rows [wave*32, wave*32+32) of each of the four planes: two 16-row pieces per plane
     const int roff0 = ((wave * 32 + prow) * K) * 2 + src_q;
     const int roff1 = roff0 + 16 * K * 2;
+    const int w_lane = lane * 16;            // W planes are piece-major (w_packed_index): byte lane*16 of the piece, its position in the soffset
     auto dma_piece = [&](int slot, int ks, int which) {     // which = 0..7: W_hi p0, W_lo p0, W_hi p1, W_lo p1, X_hi p0, X_lo p0, X_hi p1, X_lo p1
         char* sb = smem + slot * C::STAGE;
         const int soff = ks * 64;
@@ -75,9 +76,11 @@ __global__ __launch_bounds__(512, 2) void conv256_f16x3_kernel(const ConvParams 
         const int pc = (which >> 1) & 1;
         const int voff = (pc ? roff1 : roff0) | dead;
         const int d = (wave * 2 + pc) * 1024;
+        const int wvoff = w_lane | dead;
+        const int wsoff = ks * 1024 + (wave * 2 + pc) * 16 * K * 2;
         switch (which & 5) {
-            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, voff, soff, 0, 0); break;
-            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, voff, soff, 0, 0); break;
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, wvoff, wsoff, 0, 0); break;
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, wvoff, wsoff, 0, 0); break;
             case 4: __builtin_amdgcn_raw_ptr_buffer_load_lds(x_hi, MPX_LDS_PTR(sb + C::OFF_XHI + d), 16, voff, soff, 0, 0); break;
             default: __builtin_amdgcn_raw_ptr_buffer_load_lds(x_lo, MPX_LDS_PTR(sb + C::OFF_XLO + d), 16, voff, soff, 0, 0); break;
         }

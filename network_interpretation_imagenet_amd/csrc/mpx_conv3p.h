@@ -93,7 +93,6 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
     // ---- DMA addressing ----------------------------------------------------------------------------------------
     constexpr unsigned OOB = 0x80000000u;
     const int prow = lane >> 2;
-    const int wsrc_q = ((lane & 3) ^ (((prow >> 3) & 1) << 1)) * 16;     // weight rows: swizzle of mpx_conv.h
     const int xsrc_q = ((lane & 3) ^ (((prow >> 2) & 1) << 1)) * 16;     // patch rows: alignment-independent swizzle
     __amdgpu_buffer_rsrc_t x_rs_hi, x_rs_lo, w_rs_hi, w_rs_lo;
     {
@@ -119,20 +118,19 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3p_f16x3_kernel(const ConvPara
         const int off = ((((n - n_first) * H + py - 1) * W + px - 1) * cin) * 2 + xsrc_q;
         x_poff[i] = ok ? off : (int)OOB;
     }
-    int w_off[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) w_off[j] = ((j * NW + wave) * 16 + prow) * p.ktot * 2 + wsrc_q;
+    const int w_lane = lane * 16;    // piece-major planes (mpx_conv.h w_packed_index): byte lane*16 of the piece, piece position in the soffset
 
     // W(step): step = chunk*9 + tap, K offset (tap*cin + chunk*32) elements; steps past the end read nothing
     auto stage_w = [&](int slot, int chunk, int tap) {
         char* sb = smem + slot * WSTAGE;
-        const int soff = (tap * cin + chunk * 32) * 2;
+        const int soff = (tap * cin + chunk * 32) * 32;          // K step (tap*cin + chunk*32)/32, 1 KiB per step
         const int dead = chunk < nchunks ? 0 : (int)OOB;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int d = (j * NW + wave) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j] | dead, soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j] | dead, soff, 0, 0);
+            const int ps = soff + (j * NW + wave) * 16 * p.ktot * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_lane | dead, ps, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_lane | dead, ps, 0, 0);
         }
     };
     // Piece i of this wave for `chunk` into patch buffer chunk&1.  A piece beyond the allocated rows still has to be an

@@ -94,28 +94,29 @@ __global__ __launch_bounds__(C::NT, C::MINB) void convp_f16x3_kernel(const ConvP
         }
         ky = 0; kx = 0; c0 = 0; cb = 0;
     };
-    int w_off[WJ];
+    const int w_lane = lane * 16;    // piece-major planes (mpx_conv.h w_packed_index): byte lane*16 of the piece, piece position in the soffset
+    int w_piece[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int piece = C::HALF_W ? (wave % (NW / 2)) : (j * NW + wave);
-        w_off[j] = (piece * 16 + prow) * p.ktot * 2 + src_q * 2;
+        w_piece[j] = piece * 16 * p.ktot * 2;
     }
 
     auto stage_w = [&](int buf, int ks) {
         char* sb = smem + buf * WSTAGE;
-        const int soff = ks * 64;
+        const int soff = ks * 1024;
         const int dead = ks < nk ? 0 : (int)OOB;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             if (C::HALF_W) {
                 if (wave < NW / 2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + wave * 1024), 16, w_lane | dead, soff + w_piece[j], 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_off[j] | dead, soff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + wave * 1024), 16, w_lane | dead, soff + w_piece[j], 0, 0);
             } else {
                 const int d = (j * NW + wave) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_off[j] | dead, soff, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_off[j] | dead, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_lane | dead, soff + w_piece[j], 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_lane | dead, soff + w_piece[j], 0, 0);
             }
         }
     };

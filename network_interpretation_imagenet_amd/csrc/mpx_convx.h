@@ -64,8 +64,7 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         w_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_hi + (size_t)n0 * K), 0, wrec, 0x00020000);
         w_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_lo + (size_t)n0 * K), 0, wrec, 0x00020000);
     }
-    const int wrow0 = ((wave * 32 + prow) * K) * 2 + src_q;            // W rows [wave*32, +32): two pieces per plane
-    const int wrow1 = wrow0 + 16 * K * 2;
+    const int w_lane = lane * 16;                                       // W planes are piece-major (w_packed_index); rows [wave*32, +32): two pieces per plane
     const int xrow = ((wave * 16 + prow) * K) * 2 + src_q;             // X rows [wave*16, +16): one piece per plane
     int f_tile = 0, f_ks = 0, f_slot = 0;                               // the next stage to issue: tile index, K step, ring slot
     int f_dead = 0;
@@ -82,10 +81,11 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         const int soff = f_ks * 64;
         if (which < 4) {
             const int pc = which >> 1;
-            const int voff = (pc ? wrow1 : wrow0) | f_dead;
+            const int voff = w_lane | f_dead;
             const int d = (wave * 2 + pc) * 1024;
-            if ((which & 1) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, voff, soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, voff, soff, 0, 0);
+            const int wsoff = f_ks * 1024 + (wave * 2 + pc) * 16 * K * 2;
+            if ((which & 1) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, voff, wsoff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, voff, wsoff, 0, 0);
         } else {
             const int voff = xrow | f_dead;
             const int d = wave * 1024;

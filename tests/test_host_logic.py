@@ -76,6 +76,17 @@ def _desc(cin, cout, k):
     return d
 
 
+def _row_major(plane, rows, K):
+    """Undo the piece-major order of a packed weight plane (include/mpx.h, mpx_pack_conv_weights): element (row, k) sits at
+    ((((row/16)*(K/32) + k/32)*16 + row%16)*4 + ((k/8)%4 ^ ((row%16)/8)*2))*8 + k%8."""
+    row = np.arange(rows)[:, None]
+    k = np.arange(K)[None, :]
+    r = row % 16
+    at = ((((row // 16) * (K // 32) + k // 32) * 16 + r) * 4 + (((k // 8) % 4) ^ ((r // 8) * 2))) * 8 + k % 8
+    assert np.array_equal(np.sort(at.ravel()), np.arange(rows * K))          # a permutation of the plane
+    return plane.ravel()[at]
+
+
 def _pack(mpx_lib, d, w, bn, bias=None):
     hi = np.zeros((d.cout_pad, d.k_packed), dtype=np.uint16)
     lo = np.zeros_like(hi)
@@ -85,7 +96,7 @@ def _pack(mpx_lib, d, w, bn, bias=None):
     rc = mpx_lib.mpx_pack_conv_weights(C.byref(d), p(w), p(bias), p(bn[0]), p(bn[1]), p(bn[2]), p(bn[3]), 1e-5,
                                        p(hi), p(lo), p(sc), p(sh))
     assert rc == 0
-    return hi.view(np.float16), lo.view(np.float16), sc, sh
+    return _row_major(hi, d.cout_pad, d.k_packed).view(np.float16), _row_major(lo, d.cout_pad, d.k_packed).view(np.float16), sc, sh
 
 
 @pytest.mark.parametrize("cin,cout,k", [(64, 64, 3), (256, 128, 1), (3, 64, 7)])

@@ -12,7 +12,7 @@ rows, cur = {}, None
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        cur = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
         rows[cur] = {}
         continue
     for key in ("VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]"):
