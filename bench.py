@@ -251,7 +251,7 @@ def main():
                         # HBM bytes per conv launch = PMC bytes of the conv kernels per forward batch / conv launches per batch (a
                         # launch = one layer; 26 of them split their last round off into a second, small kernel dispatch)
                         "traffic": (traffic_per_batch / (conv_n / batches_profiled)) if traffic_per_batch else None,
-                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel (all conv launches)", "launches": conv_n,
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)

@@ -517,6 +517,10 @@ int default_tile(const mpx_conv_desc& d) {
     if (d.ksize == 3) return 0;
     // expanding 1x1 layers (short K, long epilogue): four waves per SIMD cover the epilogue better, -2..4 % in the
     // network; the reducing ones (long K) gain nothing from it
+    // ... and on 28x28 / 14x14 maps with K >= 128 the persistent pipelined kernel (mpx_convx.h) is 2-4 % faster still in the
+    // network (256->1024: 21.5 -> 21.0 ms, 128->512: 6.5 -> 6.2); on 7x7 maps and K = 64 it ties tile 7
+    if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout > d.cin && d.cout % 256 == 0 && d.cin % 64 == 0 && d.cin >= 128 && d.hout >= 14)
+        return 10;
     if (d.stride == 1 && d.cout > d.cin) return 7;
     // reducing / square 1x1 stride-1 layers with cout % 256 == 0: the 256x256 tile (mpx_conv256.h) halves the operand bytes
     // per MAC and runs +10..18 % (1024->256: 365 vs 322 TFLOP/s, 1024->512: 411 vs 346); expanding layers lose on it (one
