@@ -96,7 +96,8 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
  * per 32-channel chunk and the 9 taps read it at row offsets.  7 = the 128x128 tile cut into 8 waves of 32x64 (124 VGPRs: two
  * workgroups = 16 waves per CU).  8 = tile 2 as a persistent kernel with a register epilogue (cout >= 128).  9 = 256x256 tile,
  * two 64-KB stages (1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0).  10 = persistent pipelined 256x128 kernel, three
- * stages running on across tiles (as 9, cin >= 128).  A tile a layer is not eligible for returns MPX_E_ARG.
+ * stages running on across tiles (as 9, cin >= 128).  11 = persistent kernel with a 96-pixel tile's whole K extent resident in LDS and
+ * all cout tiles swept over it (as 9, cin = 128 or 256).  A tile a layer is not eligible for returns MPX_E_ARG.
  * tile < 0 = default: 64-row tiles (1 / 4) for cout <= 64; 6 where eligible with cout >= 128, 0 for the other wide 3x3 layers;
  * of the 1x1 stride-1 layers the expanding ones 10 (cin >= 128 on 28x28 / 14x14 maps) or 7, the reducing ones 9 (cout % 256 == 0)
  * or 2; 2 for everything else. */

@@ -6,6 +6,7 @@
 #include "mpx_convp.h"
 #include "mpx_conv256.h"
 #include "mpx_convx.h"
+#include "mpx_convs.h"
 
 #include <algorithm>
 #include <cmath>
@@ -454,6 +455,20 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     return 0;
 }
 
+// X-stationary expanding-1x1 kernel (mpx_convs.h, tile id 11): 1x1 stride-1 layers with cout % 256 == 0 and K = 128 or 256
+bool convs_eligible(const ConvLayer& L) { return conv256_eligible(L) && (L.cin_pad == 128 || L.cin_pad == 256); }
+
+int launch_convs(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = p.cout / ConvS::TC;
+    if (p.n_tiles_c * ConvS::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const long long n_pt = ((long long)p.M + ConvS::TP - 1) / ConvS::TP;
+    if (n_pt <= 0 || n_pt > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    const long long grid = n_pt < h->num_cus ? n_pt : h->num_cus;         // one persistent workgroup per CU
+    hipLaunchKernelGGL(convs_f16x3_kernel, dim3((unsigned)grid), dim3(ConvS::NT), ConvS::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = p.cout / Conv256::TC;
     if (p.n_tiles_c * Conv256::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
@@ -536,6 +551,7 @@ int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hi
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
     switch (tile) {
+        case 11: return launch_convs(h, p, L.d.cout_pad, st);
         case 10: return launch_convx(h, p, L.d.cout_pad, st);
         case 9: return launch_conv256(h, p, L.d.cout_pad, st);
         case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
@@ -841,6 +857,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv256_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convs_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvS::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
@@ -918,7 +935,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 10) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile > 11) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    if (tile == 11 && !convs_eligible(L))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the pixel-stationary expanding-1x1 kernel (11) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin = 128 or 256 (%s is not one)", L.d.name);
     if (tile == 10 && !convx_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent expanding-1x1 kernel (10) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0, cin >= 128 (%s is not one)", L.d.name);
     if (tile == 9 && !conv256_eligible(L))
@@ -1115,7 +1134,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10)) {
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10 || MAIN.tile == 11)) {
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

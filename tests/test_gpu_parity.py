@@ -246,6 +246,21 @@ def test_convx_persistent_expanding_kernel(eng101, name, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=10)
 
 
+@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 1), ("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv3", 161),
+                                        ("layer2.1.conv3", 3), ("layer2.1.conv3", 25), ("layer4.2.conv3", 9), ("layer3.5.conv1", 9)])
+def test_convs_pixel_stationary_expanding_kernel(eng101, name, batch):
+    """Tile id 11 (csrc/mpx_convs.h): persistent kernel that keeps a 96-pixel tile's whole K extent in LDS and sweeps all cout tiles
+    over it (two-stage weight ring that runs on across cout and pixel tiles, six-block fragment snake, register epilogue, counted
+    vmcnt waits).  Batches give a single ragged pixel tile (196 pixels = 2 full tiles + 4 pixels), one tile per workgroup, and
+    several per workgroup (161 x 196 pixels = 329 tiles on 256 CUs: pixel-tile boundaries, ragged last tile); K = 256 (8 steps per
+    cout tile) and K = 128 (4 steps, 28x28 maps).  K = 512 / 1024 layers are not eligible."""
+    i = _layer_index(eng101, name)
+    if eng101.layers[i].cin not in (128, 256):
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 11) == -1
+        return
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=11)
+
+
 @pytest.mark.parametrize("tile", [-1, 2, 7, 8])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):

@@ -47,7 +47,7 @@ for i, d in enumerate(eng.layers):
     want = y.permute(0, 2, 3, 1)
     dxh, dxl = xh.to(dev), xl.to(dev)
     drh, drl = (rh.to(dev), rl.to(dev)) if rh is not None else (None, None)
-    for tile in range(11):
+    for tile in range(12):
         if eng._lib.mpx_set_conv_tile(eng._h, i, tile) != 0:
             continue                                    # patch / 256x256 / persistent kernels: eligible layers only
         oh = torch.full((batch, d.hout, d.hout, d.cout), float("nan"), dtype=torch.float16, device=dev)
