@@ -76,7 +76,7 @@ nct = st[:, 7] * (d.cout // 256)
 print("   of the rendezvous: barrier part %.1f %% of the life" % (100 * np.median(st[:, 6] / life)))
 print("   barrier wait per K step, by wave: " + "  ".join("%d: %.0f" % (w, np.median(wbar[:, w] / nsteps)) for w in range(8)))
 for w, o in ((0, 0), (4, 4)):
-    print("   wave %d, cycles per K step: first half (18 MFMAs, 4 reads) %.0f | second half %.0f, of which its first 5 MFMAs + 4 DMA pieces %.0f" % (
+    print("   wave %d, cycles per K step: first half (18 MFMAs, 4 reads) %.0f | second half %.0f, of which its first 13 MFMAs with the 4 DMA pieces %.0f" % (
         w, np.median(seg[:, o] / nsteps), np.median(seg[:, o + 2] / nsteps), np.median(seg[:, o + 1] / nsteps)))
 print("   cycles per K step, everything included: %.0f; of which in the rendezvous %.0f" % (np.median(life / nsteps), np.median(rv / nsteps)))
 eng.close()
