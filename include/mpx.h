@@ -181,6 +181,16 @@ int mpx_set_fusion(mpx_engine* h, int on);
 int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,
                      void* out_lo, int B, int hin, int c, void* stream);
 
+/* ---- K1 + K3 in one launch: the ImageNet stem and its max pool -------------------------------------------
+ * replaces: `x = self.conv1(x); x = self.bn1(x); x = self.relu(x); x = self.maxpool(x)` (torchvision resnet.py, reached through
+ *           model(masked_img_tensor), generate_gp_training_data_imagenet.py:246): the 7x7 stride-2 conv + BN + ReLU of layer 0 reads
+ *           the engine's own staged input (mpx_mask_apply_normalize) like mpx_conv_bn_act(h, 0, ...) and writes the POOLED planes
+ *           [B][56][56][64]; a workgroup computes the 15 x 17 conv outputs under a 7 x 8 block of pooled pixels, so the 112 x 112 conv
+ *           output (3.2 MB per image) is never written nor re-read.  Bit-identical to mpx_conv_bn_act + mpx_maxpool3x3s2.
+ *           mpx_forward uses it by default (ImageNet ResNets, stem on its default tile); mpx_set_fusion(h, 0) turns it off together
+ *           with the downsample fusion. */
+int mpx_stem_conv_maxpool(mpx_engine* h, void* out_hi, void* out_lo, int B, void* stream);
+
 /* ---- K4a: global average pool [B][hw][c] -> [B][c] (nn.AvgPool2d(7) + view) ---------------- */
 int mpx_global_avgpool(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,
                        void* out_lo, int B, int hw, int c, void* stream);

@@ -100,6 +100,7 @@ struct mpx_engine {
     std::string err;
     bool in_forward = false;
     bool fuse_ds = true;    // mpx_forward runs a block's last conv and its downsample conv as one launch (mpx_set_fusion)
+    bool fuse_pool = true;  // ... and the ImageNet stem conv with its 3x3 stride-2 max pool (mpx_stem_conv_maxpool)
     bool prof_on = false;
     std::vector<ProfRec> prof_pool;
     int prof_used = 0;
@@ -657,6 +658,42 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
     return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);       // (tiles 7 and 10: the persistent kernel has no dual-operand form)
 }
 
+// The ImageNet stem (7x7 stride-2 conv + BN + ReLU) with its 3x3 stride-2 pad-1 max pool in ONE launch (mpx_conv.h, POOL): writes the
+// pooled planes [B][56][56][64]; the 112x112 conv output is never stored.  Needs the 64-row tile 1 (the stem's default).
+bool stem_pool_eligible(const mpx_engine* h) {
+    if (h->small || h->convs.empty()) return false;
+    const ConvLayer& L = h->convs[0];
+    return L.is_stem && L.d.cout == 64 && L.d.hout == 112 && (L.d.hout / 2) % POOL_PY == 0 && (L.d.hout / 2) % POOL_PX == 0 && L.d.relu;
+}
+
+int launch_stem_pool(mpx_engine* h, half_t* y_hi, half_t* y_lo, int B, hipStream_t st) {
+    const ConvLayer& L = h->convs[0];
+    if (!stem_pool_eligible(h)) return fail(h, MPX_E_STATE, "stem + max pool: this architecture has no 7x7 stem with a max pool");
+    if (!L.loaded) return fail(h, MPX_E_STATE, "layer 0 (%s) has no weights", L.d.name);
+    ConvParams p;
+    std::memset(&p, 0, sizeof p);
+    p.w_hi = L.w_hi; p.w_lo = L.w_lo; p.scale = L.scale; p.shift = L.shift;
+    p.y_hi = y_hi; p.y_lo = y_lo;
+    p.cout = L.cout_store; p.relu = L.d.relu; p.ktot = L.d.k_packed;
+    p.x_hi = h->in_hi; p.x_lo = h->in_lo;
+    p.hin = MPX_IMG_PAD; p.win = MPX_IMG_PAD; p.pix_stride = 4;
+    p.kh = kStemK; p.kw = 1; p.stride = 2; p.pad = 0; p.k_per_tap = 32;
+    p.ho = L.d.hout; p.wo = L.d.hout;
+    const long long M = (long long)B * p.ho * p.wo;
+    if (M > 0x7fffffffLL) return fail(h, MPX_E_ARG, "batch too large for 32-bit pixel indices");
+    p.M = (int)M;
+    p.n_tiles_c = 1;
+#ifdef MPX_DIAG
+    p.stamps = h->stamps;
+#endif
+    const long long nblocks = (long long)B * (p.ho / 2 / POOL_PY) * (p.wo / 2 / POOL_PX);
+    if (nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    ProfScope ps(h, st, OP_CONV, 0);
+    hipLaunchKernelGGL((conv_f16x3_kernel<ConvTile1, false, true>), dim3((unsigned)nblocks), dim3(ConvTile1::NT), ConvTile1::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Fused planes of a (main, ds) pair from the host copies of both layers.  With s3 = g3/sqrt(v3+eps) and sd likewise,
 //   bn3(W3.t2) + bnd(Wd.x) = s * ((W3 * s3/s) . t2 + (Wd * sd/s) . x) + shift3 + shiftd,   s = max(|s3|, |sd|) per channel
 // (both ratios are <= 1 in magnitude, so a vanishing gamma on either branch is harmless).  The scaled rows are rounded
@@ -839,6 +876,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile0::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile1::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile1::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
@@ -1128,9 +1167,18 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b >= 0 ? h->act_hi[b] : nullptr); };
     auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
     int rc = 0;
-    for (const Op& o : h->ops) {
+    bool skip_pool = false;
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        const Op& o = h->ops[oi];
         switch (o.kind) {
             case OP_CONV:
+                if (h->fuse_pool && o.conv == 0 && oi + 1 < h->ops.size() && h->ops[oi + 1].kind == OP_MAXPOOL && stem_pool_eligible(h) &&
+                    h->convs[0].tile == 1) {
+                    const Op& pool = h->ops[oi + 1];        // the stem writes the pooled planes; the pool op is skipped
+                    rc = launch_stem_pool(h, hi(pool.out), lo(pool.out), B, as_stream(stream));
+                    skip_pool = true;
+                    break;
+                }
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
@@ -1145,7 +1193,10 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 else
                     rc = mpx_conv_bn_act(h, o.conv, hi(o.in), lo(o.in), hi(o.res), lo(o.res), hi(o.out), lo(o.out), nullptr, B, stream);
                 break;
-            case OP_MAXPOOL: rc = mpx_maxpool3x3s2(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c, stream); break;
+            case OP_MAXPOOL:
+                if (skip_pool) { skip_pool = false; break; }
+                rc = mpx_maxpool3x3s2(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c, stream);
+                break;
             case OP_AVGPOOL: rc = mpx_global_avgpool(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin * o.hin, o.c, stream); break;
             case OP_HEAD: rc = mpx_head_softmax_gather(h, logits, label, score, pred, B, stream); break;
             case OP_AVGPAD: rc = mpx_avgpool2_pad(h, hi(o.in), lo(o.in), hi(o.out), lo(o.out), B, o.hin, o.c >> 16, o.c & 0xffff, stream); break;
@@ -1155,8 +1206,17 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     return 0;
 }
 
+int mpx_stem_conv_maxpool(mpx_engine* h, void* out_hi, void* out_lo, int B, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!out_hi || !out_lo || B <= 0) return fail(h, MPX_E_ARG, "stem + max pool: null pointer or empty batch");
+    if (B > h->max_batch) return fail(h, MPX_E_STATE, "stem + max pool: B=%d exceeds max_batch=%d", B, h->max_batch);
+    MPX_SET_DEVICE(h);
+    return launch_stem_pool(h, (half_t*)out_hi, (half_t*)out_lo, B, as_stream(stream));
+}
+
 int mpx_set_fusion(mpx_engine* h, int on) {
     if (!h) return MPX_E_ARG;
+    h->fuse_pool = on != 0;
     h->fuse_ds = on != 0;
     return 0;
 }

@@ -137,7 +137,17 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <class C, bool DUAL = false>
+// POOL (the stem of the ImageNet ResNets with its 3x3 stride-2 pad-1 max pool in the same launch): a tile is not 256 consecutive
+// output pixels but the 15 x 17 conv outputs (255 of the 256 slots) under a 7 x 8 block of POOLED pixels of one image -- pooled rows
+// 7*ty .. 7*ty+6 need conv rows 14*ty-1 .. 14*ty+13, pooled columns 8*tx .. 8*tx+7 conv columns 16*tx-1 .. 16*tx+15 -- so neighbouring
+// tiles recompute one conv row / column (15/14 x 17/16 = 1.14 x the MFMAs; the 56 x 56 pooled map is 8 x 7 tiles exactly) and the
+// 4-byte conv output (3.2 MB per image written, then read again by the pool) never exists.  The K loop is
+// unchanged; the epilogue takes the max over the fp32 tile in LDS.  Bit-identical to conv -> pool: the same accumulation per
+// conv pixel, and rounding to hi + lo is monotonic, so max-then-round = round-then-max.
+constexpr int POOL_PY = 7, POOL_PX = 8;                                    // pooled pixels per tile: rows, columns
+constexpr int POOL_CY = 2 * POOL_PY + 1, POOL_CX = 2 * POOL_PX + 1;        // conv pixels under them
+
+template <class C, bool DUAL = false, bool POOL = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,7 +171,13 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     }
     const int mt = L / p.n_tiles_c;
     const int nt = L - mt * p.n_tiles_c;
-    const int m0 = mt * TP, n0 = nt * TC;
+    const int n0 = nt * TC;
+    // POOL: tile mt = (image, ty, tx) over the pooled map; m0 = first pixel of the image
+    const int pool_tny = POOL ? p.ho / 2 / POOL_PY : 1, pool_tnx = POOL ? p.wo / 2 / POOL_PX : 1;
+    const int pool_n = mt / (pool_tny * pool_tnx);
+    const int pool_ty = (mt - pool_n * pool_tny * pool_tnx) / pool_tnx;
+    const int pool_tx = mt - pool_n * pool_tny * pool_tnx - pool_ty * pool_tnx;
+    const int m0 = POOL ? pool_n * p.ho * p.wo : mt * TP;
 
     // ---- DMA addressing: buffer_load ... lds with wave-uniform descriptors -------------------------------
     // X descriptors start at the first image this tile touches, so a lane's byte offset is small (a few
@@ -189,6 +205,17 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     int x_off0[XJ], x_iy0[XJ], x_ix0[XJ];
 #pragma unroll
     for (int i = 0; i < XJ; ++i) {
+        if (POOL) {
+            // slot s of the tile = conv pixel (14*ty - 1 + s / 17, 16*tx - 1 + s % 17); slot 255 and pixels outside the map are dead
+            const int sl = (i * NW + wave) * 16 + prow;
+            const int sy = sl / POOL_CX, sx = sl - sy * POOL_CX;
+            const int oy = 2 * POOL_PY * pool_ty - 1 + sy, ox = 2 * POOL_PX * pool_tx - 1 + sx;
+            const bool ok = sl < POOL_CY * POOL_CX && oy >= 0 && oy < p.ho && ox >= 0 && ox < p.wo && m0 < p.M;
+            x_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+            x_ix0[i] = ox * p.stride - p.pad;
+            x_off0[i] = (x_iy0[i] * p.win + x_ix0[i]) * p.pix_stride * 2 + src_q * 2;
+            continue;
+        }
         const int m = m0 + (i * NW + wave) * 16 + prow;
         const int n = m / howo;
         const int rem = m - n * howo;
@@ -456,6 +483,53 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
     }
     __syncthreads();
     MPX_STAMP(t_epi);
+    if (POOL) {
+        // Phase 2, pooled: one thread = 8 consecutive channels of one POOLED pixel = max over its 3 x 3 conv slots (the slots
+        // outside the map -- conv row / column -1 of the first tiles -- do not take part: max-pool padding)
+        constexpr int NPOOL = POOL_PY * POOL_PX;
+        const int po = p.ho / 2;
+#pragma unroll
+        for (int it = 0; it < (NPOOL + PPI - 1) / PPI; ++it) {
+            const int q = it * PPI + prow2;
+            if (!(co_ok && q < NPOOL && m0 < p.M)) continue;
+            const int py = q / POOL_PX, px = q - py * POOL_PX;
+            float best[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                if (2 * POOL_PY * pool_ty - 1 + 2 * py + dy < 0) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (2 * POOL_PX * pool_tx - 1 + 2 * px + dx < 0) continue;
+                    const int sl = (2 * py + dy) * POOL_CX + 2 * px + dx;
+                    const f4 v0 = *(const f4*)(smem + sl * RP + (((2 * g) ^ (sl & 7)) << 4));
+                    const f4 v1 = *(const f4*)(smem + sl * RP + (((2 * g + 1) ^ (sl & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        best[j] = fmaxf(best[j], v0[j]);
+                        best[4 + j] = fmaxf(best[4 + j], v1[j]);
+                    }
+                }
+            }
+            h8 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // what conv -> pool stores: the conv value rounded to hi + lo, and THAT number split again (on a tie the second split
+                // can pick the other neighbour: same value, other hi / lo pair); rounding is monotonic, so max commutes with it
+                half_t hi, lo;
+                split_f32(p.relu ? fmaxf(best[j], 0.f) : best[j], hi, lo);
+                split_f32((float)hi + (float)lo, hi, lo);
+                oh[j] = hi;
+                ol[j] = lo;
+            }
+            const size_t o = (((size_t)pool_n * po + POOL_PY * pool_ty + py) * po + POOL_PX * pool_tx + px) * p.cout + co8;
+            __builtin_nontemporal_store(oh, (h8*)(p.y_hi + o));
+            __builtin_nontemporal_store(ol, (h8*)(p.y_lo + o));
+        }
+        MPX_STAMP_WRITE(p, t_start, t_pro, t_kend, t_epi);
+        return;
+    }
     // Phase 2: one thread = 8 consecutive channels of one pixel.
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {

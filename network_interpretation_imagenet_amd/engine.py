@@ -343,8 +343,9 @@ class MaskedForwardEngine:
         _lib.check(self._h, self._lib.mpx_set_conv_tile(self._h, int(i), int(tile)), "mpx_set_conv_tile")
 
     def set_fusion(self, on=True):
-        """mpx_forward runs the first bottleneck's conv3 and its downsample conv as one K-concatenated launch (default);
-        off = two launches (bit-different results inside the same tolerance; for tests and ablation)."""
+        """mpx_forward runs the first bottleneck's conv3 and its downsample conv as one K-concatenated launch, and the ImageNet
+        stem conv with its max pool as one launch (defaults); off = separate launches (the downsample fusion changes the summation
+        order: bit-different results inside the same tolerance; the stem fusion is bit-identical; for tests and ablation)."""
         _lib.check(self._h, self._lib.mpx_set_fusion(self._h, 1 if on else 0), "mpx_set_fusion")
 
     def conv_tile(self, layer):

@@ -398,6 +398,50 @@ def test_stem_conv_from_staged_input(eng18, dev):
     assert (got - want).abs().max().item() <= 4e-6 * max(want.abs().max().item(), 1.0)
 
 
+def test_stem_conv_with_max_pool_in_one_launch(eng18, dev):
+    """mpx_stem_conv_maxpool: every workgroup computes the 15 x 17 conv outputs under a 7 x 8 block of pooled pixels and pools them
+    from its fp32 tile -- bit-identical to mpx_conv_bn_act (layer 0) followed by mpx_maxpool3x3s2, on every pixel of a ragged batch
+    (image borders = max-pool padding, tile borders = recomputed conv rows / columns)."""
+    img = synth.make_images(1, seed=3, kind="noise")[0]
+    seg = synth.grid_segments()
+    batch = 5
+    onoff = synth.random_onoff(batch, 196, seed=4)
+    eng18.stage_masks(torch.from_numpy(img).to(dev), torch.from_numpy(seg).to(dev), torch.from_numpy(onoff).to(dev), 0)
+    lib, h = eng18._lib, eng18._h
+    ch = torch.full((batch, 112, 112, 64), float("nan"), dtype=torch.float16, device=dev)
+    cl = torch.full_like(ch, float("nan"))
+    _lib.check(h, lib.mpx_conv_bn_act(h, 0, None, None, None, None, _p(ch), _p(cl), None, batch, eng18._stream()), "stem")
+    ph = torch.full((batch, 56, 56, 64), float("nan"), dtype=torch.float16, device=dev)
+    pl = torch.full_like(ph, float("nan"))
+    _lib.check(h, lib.mpx_maxpool3x3s2(h, _p(ch), _p(cl), _p(ph), _p(pl), batch, 112, 64, eng18._stream()), "maxpool")
+    fh = torch.full((batch + 1, 56, 56, 64), float("nan"), dtype=torch.float16, device=dev)      # one image of slack: nothing may be written there
+    fl = torch.full_like(fh, float("nan"))
+    _lib.check(h, lib.mpx_stem_conv_maxpool(h, _p(fh), _p(fl), batch, eng18._stream()), "stem + pool")
+    torch.cuda.synchronize()
+    assert torch.equal(fh[:batch], ph) and torch.equal(fl[:batch], pl)
+    assert torch.isnan(fh[batch]).all() and torch.isnan(fl[batch]).all()
+    assert lib.mpx_stem_conv_maxpool(h, None, _p(fl), batch, None) == -1
+    assert lib.mpx_stem_conv_maxpool(h, _p(fh), _p(fl), 10 ** 6, None) == -2
+
+
+def test_forward_with_and_without_fusions(mpx_lib, dev):
+    """mpx_set_fusion(0) runs stem / max pool and conv3 / downsample as separate launches: the stem fusion is bit-identical, the
+    downsample fusion changes the summation order (scores agree to rounding).  ResNet-18 has no 1x1-downsample fusion partner
+    eligible for K-concatenation with a 3x3 main conv, so there the whole forward must be bit-identical."""
+    eng = MaskedForwardEngine("resnet18", max_batch=64, device=0).load_state_dict(synth.make_state_dict("resnet18"))
+    try:
+        img = synth.make_images(1, seed=21, kind="noise")[0]
+        seg = synth.grid_segments()
+        onoff = synth.random_onoff(64, 196, seed=9)
+        _o, s_on, p_on = eng.score_masks(img, seg, onoff, 5)
+        eng.set_fusion(False)
+        _o, s_off, p_off = eng.score_masks(img, seg, onoff, 5)
+    finally:
+        eng.close()
+    assert np.array_equal(s_on, s_off) and np.array_equal(p_on, p_off)
+    assert np.isfinite(s_on).all() and s_on.std() > 0
+
+
 def test_conv_argument_errors(eng18, dev):
     t = torch.zeros(8, dtype=torch.float16, device=dev)
     lib, h = eng18._lib, eng18._h
