@@ -175,7 +175,31 @@ int mpx_conv_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo,
  *           tolerance; for tests and ablation).  Fused planes are built once both layers have weights. */
 int mpx_conv_dual_bn_act(mpx_engine* h, int i, const void* in_hi, const void* in_lo, const void* x_hi,
                          const void* x_lo, void* out_hi, void* out_lo, int B, void* stream);
-int mpx_set_fusion(mpx_engine* h, int on);
+/* mask bit 0: the downsample fusion above and the stem + max-pool fusion below; bit 1: the block tails of layer1
+ * (mpx_bottleneck_tail; needs bit 0 as well).  mpx_create starts with 3; 0 = one launch per layer. */
+int mpx_set_fusion(mpx_engine* h, int mask);
+
+/* ---- the tail of a 64-channel bottleneck block in ONE launch ------------------------------------------------
+ * replaces: `out = self.relu(self.bn2(self.conv2(out))); out = self.bn3(self.conv3(out)); out += identity; out = self.relu(out)`
+ *           of a layer1 Bottleneck AND `out = self.relu(self.bn1(self.conv1(x)))` of the block that follows it (torchvision
+ *           resnet.py, reached through model(masked_img_tensor), generate_gp_training_data_imagenet.py:246).  layer1 works on
+ *           56x56 maps and is HBM-bound; layer by layer a block moves 16 units (64 channels x 4 B per pixel) through HBM, this
+ *           launch 10.4: conv2's output never leaves the registers (its accumulators are conv3's MFMA operand), and the
+ *           256-channel trunk is read once -- as the identity -- instead of twice, because the next block's conv1 runs on the
+ *           output tile while it is still on chip.  Only the 64-channel conv2 input needs a one-pixel halo (everything after
+ *           the 3x3 conv is pointwise).
+ * i = index of the block's conv2 ("layer1.N.conv2"); mpx_num_bottleneck_tails / mpx_bottleneck_tail_info list the blocks
+ * that have this path (ResNet-50/101/152: the three blocks of layer1; the last one produces layer2.0.conv1's output).
+ * t1_*: conv2's input planes [B][56][56][64]; x_*: the block's identity planes [B][56][56][256] -- for a block with a
+ * downsample branch (layer1.0) the BLOCK INPUT planes [B][56][56][64], the branch being K-concatenated as in
+ * mpx_conv_dual_bn_act; out_*: block output [B][56][56][256]; next_*: the following conv1's output [B][56][56][64 or 128].
+ * All four plane pairs must be distinct buffers (workgroups read t1's halo while others write).  Same arithmetic as the
+ * layer-by-layer path up to fp32 summation order.  mpx_forward takes this path by default. */
+int mpx_bottleneck_tail(mpx_engine* h, int i, const void* t1_hi, const void* t1_lo, const void* x_hi, const void* x_lo,
+                        void* out_hi, void* out_lo, void* next_hi, void* next_lo, int B, void* stream);
+int mpx_num_bottleneck_tails(const mpx_engine* h);
+/* layer indices of tail k: its conv2, conv3, downsample conv (-1 if none) and the following block's conv1; any pointer may be NULL */
+int mpx_bottleneck_tail_info(const mpx_engine* h, int k, int* conv2, int* conv3, int* downsample, int* next_conv1);
 
 /* ---- K3: maxpool 3x3 s2 p1 (nn.MaxPool2d inside the same forward), NHWC split planes ------ */
 int mpx_maxpool3x3s2(mpx_engine* h, const void* in_hi, const void* in_lo, void* out_hi,

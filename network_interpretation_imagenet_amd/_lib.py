@@ -52,6 +52,9 @@ SIGNATURES = {
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_conv_dual_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_set_fusion": (_i, [_vp, _i]),
+    "mpx_bottleneck_tail": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mpx_num_bottleneck_tails": (_i, [_vp]),
+    "mpx_bottleneck_tail_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mpx_stem_conv_maxpool": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mpx_maxpool3x3s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mpx_global_avgpool": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

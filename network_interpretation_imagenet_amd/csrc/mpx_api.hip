@@ -7,6 +7,7 @@
 #include "mpx_conv256.h"
 #include "mpx_convx.h"
 #include "mpx_convs.h"
+#include "mpx_btail.h"
 
 #include <algorithm>
 #include <cmath>
@@ -29,7 +30,7 @@ constexpr int kProfilePairs = 4096;
 constexpr size_t kActElemsPerImage = 112 * 112 * 64;   // ImageNet: largest activation (stem output, = 56*56*256)
 constexpr int kSmallCPad = 32;                         // small nets: channels are stored padded to a multiple of 32
 
-enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3, OP_AVGPAD = 4 };
+enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3, OP_AVGPAD = 4, OP_BTAIL = 5 };
 enum Buf { BUF_INPUT = -1, BUF_POOL = -2, BUF_NONE = -3 };
 
 struct ConvLayer {
@@ -64,6 +65,18 @@ struct Op {
     int in, out, res;
     int hin, c;     // pools
     int in2;        // fused main conv: buffer of the block input (the downsample branch's operand), else BUF_NONE
+    int z = BUF_NONE;   // OP_BTAIL: buffer of the next block's conv1 output; `conv` = index into mpx_engine::tails,
+                        // in = t1, res = block input / identity, out = block output
+};
+
+// A 64-channel bottleneck block whose tail runs as ONE launch (mpx_btail.h): conv2 -> conv3 (+ identity or K-concatenated
+// downsample branch) -> the next block's conv1.  Weights: conv2's and next1's packed planes as they are; conv3's (or the fused
+// conv3 | downsample planes') with columns [0,64) K-permuted into planes of its own.
+struct TailBlock {
+    int c2 = -1, c3 = -1, ds = -1, next1 = -1;
+    half_t* w3p_hi = nullptr;
+    half_t* w3p_lo = nullptr;
+    bool ready = false;
 };
 
 struct ProfRec {
@@ -87,6 +100,10 @@ struct mpx_engine {
     int feat = 0;
     std::vector<ConvLayer> convs;
     std::vector<Op> ops;
+    std::vector<Op> ops_bt;         // the same network with layer1's block tails as OP_BTAIL (empty if the arch has none)
+    std::vector<TailBlock> tails;
+    int ops_bt_x = 0;               // buffer of the last block's output in ops_bt
+    bool fuse_bt = true;            // mpx_forward uses ops_bt when every tail is ready (mpx_set_fusion bit 1)
     char* arena = nullptr;
     size_t arena_bytes = 0;
     half_t* in_hi = nullptr;
@@ -199,6 +216,8 @@ int build_topology(mpx_engine* h) {
     add_op(OP_MAXPOOL, -1, 0, 1, BUF_NONE, 112, 64);
     int X = 1, cin = 64, hcur = 56;
     const int widths[4] = {64, 128, 256, 512};
+    struct BlockRec { int c1, c2, c3, ds, hin; };
+    std::vector<BlockRec> blocks;       // bottleneck blocks in forward order (the block-tail plan below is built from them)
     for (int s = 0; s < 4; ++s) {
         const int w = widths[s];
         for (int b = 0; b < depths[s]; ++b) {
@@ -222,29 +241,91 @@ int build_topology(mpx_engine* h) {
                 add_op(OP_CONV, c, T1, O, res, 0, 0);
                 X = O;
             } else {
+                BlockRec R{-1, -1, -1, -1, hcur};
                 const int T1 = pick({X});
-                c = add_conv(p + "conv1", p + "bn1", cin, w, 1, 1, 0, hcur, 1, 0);
+                R.c1 = c = add_conv(p + "conv1", p + "bn1", cin, w, 1, 1, 0, hcur, 1, 0);
                 add_op(OP_CONV, c, X, T1, BUF_NONE, 0, 0);
                 const int T2 = pick({X, T1});
-                c = add_conv(p + "conv2", p + "bn2", w, w, 3, stride, 1, hcur, 1, 0);
+                R.c2 = c = add_conv(p + "conv2", p + "bn2", w, w, 3, stride, 1, hcur, 1, 0);
                 add_op(OP_CONV, c, T1, T2, BUF_NONE, 0, 0);
                 int res = X, dsc = -1;
                 if (ds) {
                     const int T3 = pick({X, T1, T2});
-                    dsc = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
+                    R.ds = dsc = add_conv(p + "downsample.0", p + "downsample.1", cin, w * exp, 1, stride, 0, hcur, 0, 0);
                     add_op(OP_CONV, dsc, X, T3, BUF_NONE, 0, 0);
                     res = T3;
                 }
-                c = add_conv(p + "conv3", p + "bn3", w, w * exp, 1, 1, 0, hout, 1, 1);
+                R.c3 = c = add_conv(p + "conv3", p + "bn3", w, w * exp, 1, 1, 0, hout, 1, 1);
                 add_op(OP_CONV, c, T2, T1, res, 0, 0, ds ? X : BUF_NONE);   // T1 is dead after conv2
                 if (ds) {
                     h->convs[c].fuse_partner = dsc; h->convs[c].fuse_main = true;
                     h->convs[dsc].fuse_partner = c;
                 }
+                blocks.push_back(R);
                 X = T1;
             }
             cin = w * exp;
             hcur = hout;
+        }
+    }
+    // Block-tail plan (mpx_btail.h): a block whose conv2 is 64 -> 64 3x3 stride 1 on a 56x56 map, whose conv3 is 64 -> 256 and
+    // whose successor starts with a 1x1 stride-1 conv 256 -> 64 / 128 (layer1 of ResNet-50 / 101 / 152) runs conv2, conv3 (+ the
+    // identity or the K-concatenated downsample branch) and the successor's conv1 as ONE launch.  Four distinct buffers are live
+    // across such a launch (block input, t1, block output, next t1): other workgroups still read t1's halo while this one writes.
+    {
+        auto tail_ok = [&](size_t k) {
+            if (k + 1 >= blocks.size()) return false;
+            const mpx_conv_desc& d2 = h->convs[blocks[k].c2].d;
+            const mpx_conv_desc& d3 = h->convs[blocks[k].c3].d;
+            const mpx_conv_desc& n1 = h->convs[blocks[k + 1].c1].d;
+            if (!(d2.cin == BT_MID && d2.cout == BT_MID && d2.ksize == 3 && d2.stride == 1 && d2.hin == 56)) return false;
+            if (!(d3.cin == BT_MID && d3.cout == BT_OUT)) return false;
+            if (blocks[k].ds >= 0) {
+                const mpx_conv_desc& dd = h->convs[blocks[k].ds].d;
+                if (!(dd.cin == BT_MID && dd.stride == 1 && dd.ksize == 1)) return false;
+            }
+            return n1.cin == BT_OUT && n1.ksize == 1 && n1.stride == 1 && n1.hin == 56 && (n1.cout == 64 || n1.cout == 128) &&
+                   !(blocks[k].ds >= 0 && n1.cout != 64);
+        };
+        bool any = false;
+        for (size_t k = 0; k < blocks.size(); ++k) any |= tail_ok(k);
+        if (any) {
+            std::vector<Op>& out = h->ops_bt;
+            out.push_back(h->ops[0]);       // stem conv, max pool
+            out.push_back(h->ops[1]);
+            int Xb = 1, T1c = -100;         // T1c: buffer of a t1 that the previous tail launch has already written
+            for (size_t k = 0; k < blocks.size(); ++k) {
+                const BlockRec& R = blocks[k];
+                int T1 = T1c;
+                if (T1 < 0) {
+                    T1 = pick({Xb});
+                    out.push_back(Op{OP_CONV, R.c1, Xb, T1, BUF_NONE, 0, 0, BUF_NONE});
+                }
+                T1c = -100;
+                if (tail_ok(k)) {
+                    TailBlock tb;
+                    tb.c2 = R.c2; tb.c3 = R.c3; tb.ds = R.ds; tb.next1 = blocks[k + 1].c1;
+                    h->tails.push_back(tb);
+                    const int O = pick({Xb, T1}), Z = pick({Xb, T1, O});
+                    Op o{OP_BTAIL, (int)h->tails.size() - 1, T1, O, Xb, 0, 0, BUF_NONE};
+                    o.z = Z;
+                    out.push_back(o);
+                    Xb = O;
+                    T1c = Z;
+                    continue;
+                }
+                const int T2 = pick({Xb, T1});
+                out.push_back(Op{OP_CONV, R.c2, T1, T2, BUF_NONE, 0, 0, BUF_NONE});
+                int res = Xb;
+                if (R.ds >= 0) {
+                    const int T3 = pick({Xb, T1, T2});
+                    out.push_back(Op{OP_CONV, R.ds, Xb, T3, BUF_NONE, 0, 0, BUF_NONE});
+                    res = T3;
+                }
+                out.push_back(Op{OP_CONV, R.c3, T2, T1, res, 0, 0, R.ds >= 0 ? Xb : BUF_NONE});
+                Xb = T1;
+            }
+            h->ops_bt_x = Xb;
         }
     }
     h->feat = cin;
@@ -253,6 +334,11 @@ int build_topology(mpx_engine* h) {
     h->convs[c].is_fc = true;
     add_op(OP_CONV, c, BUF_POOL, BUF_NONE, BUF_NONE, 0, 0);
     add_op(OP_HEAD, -1, BUF_NONE, BUF_NONE, BUF_NONE, 0, 0);
+    if (!h->ops_bt.empty()) {
+        h->ops_bt.push_back(Op{OP_AVGPOOL, -1, h->ops_bt_x, BUF_POOL, BUF_NONE, hcur, cin, BUF_NONE});
+        h->ops_bt.push_back(h->ops[h->ops.size() - 2]);
+        h->ops_bt.push_back(h->ops[h->ops.size() - 1]);
+    }
     return 0;
 }
 
@@ -694,6 +780,79 @@ int launch_stem_pool(mpx_engine* h, half_t* y_hi, half_t* y_lo, int B, hipStream
     return 0;
 }
 
+// K permutation of a block tail's conv3 operand (mpx_btail.h): K position 8g + j of a 32-wide step holds channel (j>>2)*16 + 4g + (j&3),
+// because that is where the conv2 accumulators of a lane group g sit (D layout of v_mfma_f32_16x16x32_f16: registers 4g .. 4g+3 of
+// two stacked 16-row fragments).
+inline int bt_perm_channel(int kpos) {
+    const int s = kpos >> 5, q = kpos & 31, g = q >> 3, j = q & 7;
+    return 32 * s + (j >> 2) * 16 + 4 * g + (j & 3);
+}
+
+// Upload the K-permuted copy of packed planes `hi`/`lo` ([rows >= 256][K], piece-major, host) into the tail's own planes:
+// columns [0,64) permuted, columns [64,K) (the downsample branch of a DUAL tail) as they are.
+int upload_tail_planes(mpx_engine* h, TailBlock& tb, const std::vector<uint16_t>& hi, const std::vector<uint16_t>& lo, int K) {
+    std::vector<uint16_t> ph((size_t)BT_OUT * K), pl((size_t)BT_OUT * K);
+    for (int row = 0; row < BT_OUT; ++row)
+        for (int k = 0; k < K; ++k) {
+            const int src = k < BT_MID ? bt_perm_channel(k) : k;
+            ph[w_packed_index(row, k, K)] = hi[w_packed_index(row, src, K)];
+            pl[w_packed_index(row, k, K)] = lo[w_packed_index(row, src, K)];
+        }
+    MPX_HIP(h, hipMemcpy(tb.w3p_hi, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+    MPX_HIP(h, hipMemcpy(tb.w3p_lo, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+    tb.ready = true;
+    return 0;
+}
+
+TailBlock* tail_of_conv3(mpx_engine* h, int c3) {
+    for (TailBlock& tb : h->tails)
+        if (tb.c3 == c3) return &tb;
+    return nullptr;
+}
+
+bool tails_ready(const mpx_engine* h) {
+    if (h->tails.empty()) return false;
+    for (const TailBlock& tb : h->tails)
+        if (!tb.ready || !h->convs[tb.c2].loaded || !h->convs[tb.next1].loaded) return false;
+    return true;
+}
+
+// One block tail (mpx_btail.h): t1 planes [B][56][56][64], x = identity planes [B][56][56][256] (first block of layer1: the block
+// input [B][56][56][64]), y = block output [B][56][56][256], z = the next block's conv1 output [B][56][56][64 | 128].
+int launch_btail(mpx_engine* h, int ti, const half_t* t_hi, const half_t* t_lo, const half_t* x_hi, const half_t* x_lo,
+                 half_t* y_hi, half_t* y_lo, half_t* z_hi, half_t* z_lo, int B, hipStream_t st) {
+    const TailBlock& tb = h->tails[ti];
+    const ConvLayer& L2 = h->convs[tb.c2];
+    const ConvLayer& L3 = h->convs[tb.c3];
+    const ConvLayer& N1 = h->convs[tb.next1];
+    if (!tb.ready || !L2.loaded || !N1.loaded) return fail(h, MPX_E_STATE, "block tail %s: weights missing", L2.d.name);
+    const bool dual = tb.ds >= 0;
+    BtParams p;
+    std::memset(&p, 0, sizeof p);
+    p.t_hi = t_hi; p.t_lo = t_lo;
+    p.w2_hi = L2.w_hi; p.w2_lo = L2.w_lo; p.sc2 = L2.scale; p.sh2 = L2.shift;
+    p.w3_hi = tb.w3p_hi; p.w3_lo = tb.w3p_lo;
+    p.sc3 = dual ? L3.fscale : L3.scale; p.sh3 = dual ? L3.fshift : L3.shift;
+    p.r_hi = x_hi; p.r_lo = x_lo; p.y_hi = y_hi; p.y_lo = y_lo;
+    p.w1_hi = N1.w_hi; p.w1_lo = N1.w_lo; p.sc1 = N1.scale; p.sh1 = N1.shift;
+    p.z_hi = z_hi; p.z_lo = z_lo;
+    p.B = B; p.H = L2.d.hin; p.W = L2.d.hin;
+    if (p.H % BT_TY || p.W % BT_TX) return fail(h, MPX_E_INTERNAL, "block tail: %dx%d map is not a whole number of 8x14 tiles", p.H, p.W);
+    p.tiles_x = p.W / BT_TX;
+    p.tiles_per_img = (p.H / BT_TY) * p.tiles_x;
+    const long long n_tiles = (long long)B * p.tiles_per_img;
+    if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) return fail(h, MPX_E_ARG, "block tail: batch out of range");
+    p.n_tiles = (int)n_tiles;
+    const long long resident = 2LL * h->num_cus;                       // two 80-KB workgroups per CU
+    const unsigned grid = (unsigned)std::min<long long>(resident / 8 * 8, (n_tiles + 7) / 8 * 8);
+    ProfScope ps(h, st, OP_CONV, tb.c2);
+    if (dual) hipLaunchKernelGGL(btail_f16x3_kernel<BtDualC64>, dim3(grid), dim3(256), BtDualC64::LDS, st, p);
+    else if (N1.d.cout == 128) hipLaunchKernelGGL(btail_f16x3_kernel<BtResC128>, dim3(grid), dim3(256), BtResC128::LDS, st, p);
+    else hipLaunchKernelGGL(btail_f16x3_kernel<BtResC64>, dim3(grid), dim3(256), BtResC64::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Fused planes of a (main, ds) pair from the host copies of both layers.  With s3 = g3/sqrt(v3+eps) and sd likewise,
 //   bn3(W3.t2) + bnd(Wd.x) = s * ((W3 * s3/s) . t2 + (Wd * sd/s) . x) + shift3 + shiftd,   s = max(|s3|, |sd|) per channel
 // (both ratios are <= 1 in magnitude, so a vanishing gamma on either branch is harmless).  The scaled rows are rounded
@@ -735,10 +894,8 @@ int build_fused(mpx_engine* h, int main) {
     MPX_HIP(h, hipMemcpy(L.fscale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.fshift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     L.fused_loaded = true;
-    for (ConvLayer* q : {&L, &D}) {          // the host copies are no longer needed
-        std::vector<float>().swap(q->hw); std::vector<float>().swap(q->hgamma); std::vector<float>().swap(q->hbeta);
-        std::vector<float>().swap(q->hmean); std::vector<float>().swap(q->hvar);
-    }
+    // (the host copies of both layers stay: they are small, and reloading ONE layer of the pair later must rebuild these planes)
+    if (TailBlock* tb = tail_of_conv3(h, main)) return upload_tail_planes(h, *tb, hi, lo, K);
     return 0;
 }
 
@@ -834,6 +991,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         if (L.fuse_main)
             wbytes += 2 * round_up((size_t)L.d.cout_pad * (L.d.cin + h->convs[L.fuse_partner].d.cin) * 2, 256) + 2 * round_up((size_t)L.d.cout_pad * 4, 256);
     }
+    for (const TailBlock& tb : h->tails) wbytes += 2 * round_up((size_t)BT_OUT * (tb.ds >= 0 ? 2 : 1) * BT_MID * 2, 256);
     const size_t scratch_bytes = 4096 * sizeof(float);
     const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes;
     e = hipMalloc((void**)&h->arena, total);
@@ -866,6 +1024,11 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
             L.fscale = (float*)take(sb);
             L.fshift = (float*)take(sb);
         }
+    }
+    for (TailBlock& tb : h->tails) {
+        const size_t pb = round_up((size_t)BT_OUT * (tb.ds >= 0 ? 2 : 1) * BT_MID * 2, 256);
+        tb.w3p_hi = (half_t*)take(pb);
+        tb.w3p_lo = (half_t*)take(pb);
     }
     // the never-written borders (ImageNet) / padding channels (small nets) of the input staging must be zero, and so must
     // the pooled planes' padding channels
@@ -901,6 +1064,12 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtResC64>, hipFuncAttributeMaxDynamicSharedMemorySize, BtResC64::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtResC128>, hipFuncAttributeMaxDynamicSharedMemorySize, BtResC128::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtDualC64>, hipFuncAttributeMaxDynamicSharedMemorySize, BtDualC64::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
@@ -955,6 +1124,14 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv
     MPX_HIP(h, hipMemcpy(L.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     L.loaded = true;
+    if (TailBlock* tb = tail_of_conv3(h, i)) {
+        if (tb->ds < 0) {               // identity tail: the permuted copy of this layer's own planes (scale / shift are shared)
+            rc = upload_tail_planes(h, *tb, hi, lo, L.d.k_packed);
+            if (rc) return rc;
+        } else {
+            tb->ready = false;          // rebuilt by build_fused below once both layers of the pair are in
+        }
+    }
     if (L.fuse_partner >= 0) {
         const size_t nw = (size_t)L.d.cout * L.d.cin;       // both layers of a pair are 1x1
         L.hw.assign(w, w + nw);
@@ -1168,13 +1345,23 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
     int rc = 0;
     bool skip_pool = false;
-    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
-        const Op& o = h->ops[oi];
+    // layer1's block tails as single launches (mpx_btail.h) whenever their planes are in and no tile override asks for the
+    // layer-by-layer kernels of those layers
+    bool use_bt = h->fuse_bt && h->fuse_ds && tails_ready(h);
+    for (const TailBlock& tb : h->tails)
+        for (int li : {tb.c2, tb.c3, tb.next1})
+            use_bt = use_bt && h->convs[li].tile == default_tile(h->convs[li].d);
+    const std::vector<Op>& ops = use_bt ? h->ops_bt : h->ops;
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        const Op& o = ops[oi];
         switch (o.kind) {
+            case OP_BTAIL:
+                rc = launch_btail(h, o.conv, hi(o.in), lo(o.in), hi(o.res), lo(o.res), hi(o.out), lo(o.out), hi(o.z), lo(o.z), B, as_stream(stream));
+                break;
             case OP_CONV:
-                if (h->fuse_pool && o.conv == 0 && oi + 1 < h->ops.size() && h->ops[oi + 1].kind == OP_MAXPOOL && stem_pool_eligible(h) &&
+                if (h->fuse_pool && o.conv == 0 && oi + 1 < ops.size() && ops[oi + 1].kind == OP_MAXPOOL && stem_pool_eligible(h) &&
                     h->convs[0].tile == 1) {
-                    const Op& pool = h->ops[oi + 1];        // the stem writes the pooled planes; the pool op is skipped
+                    const Op& pool = ops[oi + 1];        // the stem writes the pooled planes; the pool op is skipped
                     rc = launch_stem_pool(h, hi(pool.out), lo(pool.out), B, as_stream(stream));
                     skip_pool = true;
                     break;
@@ -1214,10 +1401,36 @@ int mpx_stem_conv_maxpool(mpx_engine* h, void* out_hi, void* out_lo, int B, void
     return launch_stem_pool(h, (half_t*)out_hi, (half_t*)out_lo, B, as_stream(stream));
 }
 
-int mpx_set_fusion(mpx_engine* h, int on) {
+int mpx_set_fusion(mpx_engine* h, int mask) {
     if (!h) return MPX_E_ARG;
-    h->fuse_pool = on != 0;
-    h->fuse_ds = on != 0;
+    h->fuse_pool = (mask & 1) != 0;
+    h->fuse_ds = (mask & 1) != 0;
+    h->fuse_bt = (mask & 2) != 0;
+    return 0;
+}
+
+int mpx_bottleneck_tail(mpx_engine* h, int i, const void* t1_hi, const void* t1_lo, const void* x_hi, const void* x_lo,
+                        void* out_hi, void* out_lo, void* next_hi, void* next_lo, int B, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (B <= 0 || !t1_hi || !t1_lo || !x_hi || !x_lo || !out_hi || !out_lo || !next_hi || !next_lo)
+        return fail(h, MPX_E_ARG, "bottleneck_tail: null planes or empty batch");
+    int ti = -1;
+    for (size_t k = 0; k < h->tails.size(); ++k)
+        if (h->tails[k].c2 == i) ti = (int)k;
+    if (ti < 0) return fail(h, MPX_E_ARG, "bottleneck_tail: layer %d is not the conv2 of a block whose tail runs as one launch", i);
+    MPX_SET_DEVICE(h);
+    return launch_btail(h, ti, (const half_t*)t1_hi, (const half_t*)t1_lo, (const half_t*)x_hi, (const half_t*)x_lo, (half_t*)out_hi,
+                        (half_t*)out_lo, (half_t*)next_hi, (half_t*)next_lo, B, as_stream(stream));
+}
+
+int mpx_num_bottleneck_tails(const mpx_engine* h) { return h ? (int)h->tails.size() : MPX_E_ARG; }
+
+int mpx_bottleneck_tail_info(const mpx_engine* h, int k, int* conv2, int* conv3, int* downsample, int* next_conv1) {
+    if (!h || k < 0 || k >= (int)h->tails.size()) return MPX_E_ARG;
+    if (conv2) *conv2 = h->tails[k].c2;
+    if (conv3) *conv3 = h->tails[k].c3;
+    if (downsample) *downsample = h->tails[k].ds;
+    if (next_conv1) *next_conv1 = h->tails[k].next1;
     return 0;
 }
 

@@ -1,0 +1,539 @@
+// mpx_btail.h -- the TAIL of a 64-channel bottleneck block in ONE launch (f16x3 arithmetic of mpx_conv.h):
+//
+//     t2  = relu(bn2(conv2_3x3(t1)))                              64 -> 64, stride 1, pad 1      (never leaves the registers)
+//     out = relu(bn3(conv3_1x1(t2)) + identity)                   64 -> 256                      (written: the next block's identity)
+//           DUAL (first block of layer1): identity = bn_d(conv_d_1x1(x)) K-concatenated as in mpx_conv.h's DUAL kernel
+//     t1' = relu(bn1'(conv1'_1x1(out)))                           256 -> C1 (64, or 128 for layer2.0.conv1; 0 = none)
+//                                                                 the NEXT block's first conv, from the tile that is still on chip
+//
+// Why: layer1 of the bottleneck ResNets is HBM-bound (56x56 maps; 24 % of the network's bytes for 3.5 % of its FLOPs).  Layer by
+// layer a block moves, per pixel and in units of 64 channels x 4 B: conv1 r4 w1, conv2 r1 w1, conv3 r1 + r4 (identity) + w4 = 16.
+// Here: t1 tile with a one-pixel halo r1.4, identity r4, out w4, t1' w1 = 10.4 -- t2 is never stored, and the 256-channel trunk is
+// read ONCE per block (as the identity) instead of twice.  Everything behind conv2 is pointwise, so only the 64-channel t1 needs a
+// halo; nothing is recomputed.
+//
+// Workgroup = 4 waves, 80 KB LDS, two workgroups per CU (one's HBM-bound chunk epilogues overlap the other's MFMA-bound conv2),
+// persistent over tiles.  Tile = 8 rows x 14 columns of one image (56 = 7 x 8 = 4 x 14); a 16-lane pixel fragment is one tile row
+// (lanes 14, 15 are dead: 12.5 % of the MFMA columns, nothing else).  Waves split the PIXELS (wave w = tile rows 2w, 2w+1 = two
+// fragments) and own all channels of them, so a wave's conv2 accumulators (D layout: lane = pixel, registers = channels) ARE the
+// B operand of its conv3 MFMAs under a permutation of K that is baked into the packed conv3 weights (mpx_api.hip, pack_w3_perm):
+// K position 8g + j of a 32-wide step holds channel (j>>2)*16 + 4g + (j&3).
+//
+// LDS: [scale / shift vectors][t1 patch: 10 x 16 pixels x 64 channels x (hi, lo) = 40 KB; after conv2 the same bytes are four
+// wave-private 8-KB staging areas][weight ring: 4 stages of 64 rows x 32 k x (hi, lo) = 8 KB].  The weight stream of a tile is
+// 18 stages of conv2 (tap-major), then per 64-channel chunk of `out`: S3 stages of conv3 rows [64c, 64c+64) and S1 stages of
+// conv1' columns [64c, 64c+64); stage numbers run on across tiles (the stream is the same for every tile).
+// Per chunk: conv3 MFMAs -> acc * scale + shift as fp32 into the wave's staging area -> read back as (pixel, 8 channels) per lane:
+// identity lines loaded and `out` lines stored as whole 128-B lines -> the same values, split into hi + lo, back into the staging
+// area in operand layout -> B fragments of conv1' (natural K order).  No block barrier in the epilogues: a wave only touches its own
+// pixels.
+//
+// vmcnt bookkeeping: LDS-DMAs, loads and stores retire in issue order.  Per step a wave issues one stage (2 pieces), then possibly
+// 8 identity loads (for the next chunk) and, at the end of a chunk's last conv3 step, 8 stores; BtSched computes the immediate of
+// every counted wait from that program.  The per-lane scale / shift vectors come from LDS so that no other vector-memory
+// instruction exists.  At a tile boundary the wave drains (the patch must land; the partner workgroup covers).
+#pragma once
+#include "mpx_conv.h"
+#include <type_traits>
+
+namespace mpx {
+
+struct BtParams {
+    const half_t* t_hi;      // conv2 input planes [B][H][W][64]
+    const half_t* t_lo;
+    const half_t* w2_hi;     // conv2 weights, piece-major [>= 64][576] (mpx_pack_conv_weights)
+    const half_t* w2_lo;
+    const float* sc2;
+    const float* sh2;
+    const half_t* w3_hi;     // conv3 weights, piece-major [256][64] (DUAL: [256][128]), columns [0,64) K-permuted
+    const half_t* w3_lo;
+    const float* sc3;
+    const float* sh3;
+    const half_t* r_hi;      // identity planes [B][H][W][256]; DUAL: the block input planes [B][H][W][64]
+    const half_t* r_lo;
+    half_t* y_hi;            // block output planes [B][H][W][256]
+    half_t* y_lo;
+    const half_t* w1_hi;     // next conv1 weights, piece-major [>= C1][256]
+    const half_t* w1_lo;
+    const float* sc1;
+    const float* sh1;
+    half_t* z_hi;            // its output planes [B][H][W][C1]
+    half_t* z_lo;
+    int B, H, W;
+    int tiles_x;             // W / 14
+    int tiles_per_img;       // (H / 8) * (W / 14)
+    int n_tiles;             // B * tiles_per_img
+};
+
+constexpr int BT_TY = 8, BT_TX = 14;                    // output pixels of a tile: rows x columns
+constexpr int BT_PY = BT_TY + 2;                        // patch rows; a patch row is 16 pixels (columns -1 .. 14 of the tile)
+constexpr int BT_NRING = 4;
+constexpr int BT_STAGE = 8192;                          // [hi: 64 rows x 64 B][lo]
+constexpr int BT_BLK = BT_PY * 16 * 64;                 // one (32-channel chunk, plane) block of the patch: 160 rows x 64 B
+// LDS map.  The vectors come first and the ring last so that every per-lane base address + immediate offset of the many
+// unrolled ds_read / ds_write stays below the 64-KB reach of the instruction's offset field (otherwise hipcc keeps one
+// address VGPR per access).
+constexpr int BT_OFF_VEC = 0;                           // scale / shift vectors, <= 4 KB
+constexpr int BT_OFF_PATCH = 4096;
+constexpr int BT_OFF_RING = BT_OFF_PATCH + 4 * BT_BLK + 256;  // + slack: the dead lanes of the last patch row read 2 rows further
+constexpr int BT_MID = 64, BT_OUT = 256;
+
+template <bool DUAL_, int C1_>
+struct BtCfg {
+    static constexpr bool DUAL = DUAL_;
+    static constexpr int C1 = C1_;
+    static constexpr int N2 = 18;                       // conv2 steps: 9 taps x 2 chunks of 32 channels
+    static constexpr int S3 = DUAL ? 4 : 2;             // conv3 steps per output chunk (K = 64, + 64 of the downsample branch)
+    static constexpr int H1 = C1 / 64;                  // 64-row blocks of conv1'
+    static constexpr int S1 = 2 * H1;                   // conv1' steps per chunk
+    static constexpr int SC = S3 + S1;
+    static constexpr int NSTEP = N2 + 4 * SC;
+    static constexpr int NVEC = 2 * (BT_MID + BT_OUT + (C1 ? C1 : 4));    // floats: sc2 sh2 sc3 sh3 sc1 sh1
+    static constexpr int LDS = BT_OFF_RING + BT_NRING * BT_STAGE;
+    static_assert(NVEC * 4 <= BT_OFF_PATCH, "vectors overflow their LDS area");
+    static_assert(C1 == 0 || C1 == 64 || C1 == 128, "conv1' has 0, 64 or 128 output channels");
+
+    // ---- the vector-memory program of one tile, per wave (see the header) ----
+    static constexpr int mod(int j) { return ((j % NSTEP) + NSTEP) % NSTEP; }
+    static constexpr int JX = 2;                        // DUAL: step behind whose stage the 8 block-input fragment loads are issued
+    static constexpr int pre(int j) {                   // loads issued right behind the stage of step j
+        j = mod(j);
+        if (DUAL) return j == JX ? 8 : 0;
+        if (j == N2 - 3) return 8;                                          // identity lines of chunk 0
+        for (int c = 1; c < 4; ++c)
+            if (j == N2 + (c - 1) * SC + S3) return 8;                      // ... of chunk c, in the first conv1' step of chunk c-1
+        return 0;
+    }
+    static constexpr int post(int j) {                  // stores at the end of step j
+        j = mod(j);
+        int n = 0;
+        for (int c = 0; c < 4; ++c)
+            if (j == N2 + c * SC + S3 - 1) n += 8;                          // `out` lines of chunk c
+        if (j == NSTEP - 1) n += 8 * H1;                                    // t1' lines
+        return n;
+    }
+    static constexpr int all(int j) { return 2 + pre(j) + post(j); }
+    // top of step j: the stage of step j (issued first thing in step j-3) has landed; everything behind it may be in flight
+    static constexpr int wait_top(int j) { return pre(j - 3) + post(j - 3) + all(j - 2) + all(j - 1); }
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr bool DUAL = C::DUAL;
+    constexpr int C1 = C::C1, N2 = C::N2, S3 = C::S3, S1 = C::S1, SC = C::SC, H1 = C::H1, NSTEP = C::NSTEP;
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 15, lg = lane >> 4;
+
+    // tiles of this workgroup: blocks of one XCD (b % 8) walk neighbouring tiles (shared halo rows stay in that XCD's L2)
+    const int G = gridDim.x;                                            // a multiple of 8 (host)
+    const int v0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if (v0 >= p.n_tiles) return;
+    const int my_tiles = (p.n_tiles - 1 - v0) / G + 1;
+
+    char* const ring = smem + BT_OFF_RING;
+    char* const patch = smem + BT_OFF_PATCH;
+    char* const stg = patch + wave * 8192;                             // wave-private staging (inside the patch bytes)
+    float* const vec = (float*)(smem + BT_OFF_VEC);
+    constexpr int V_SC2 = 0, V_SH2 = BT_MID, V_SC3 = 2 * BT_MID, V_SH3 = 2 * BT_MID + BT_OUT, V_SC1 = 2 * BT_MID + 2 * BT_OUT,
+                  V_SH1 = V_SC1 + (C1 ? C1 : 4);
+
+    // scale / shift vectors -> LDS (published by the first barrier below)
+    for (int i = tid; i < C::NVEC; i += 256) {
+        float v = 0.f;
+        if (i < V_SH2) v = p.sc2[i];
+        else if (i < V_SC3) v = p.sh2[i - V_SH2];
+        else if (i < V_SH3) v = p.sc3[i - V_SC3];
+        else if (i < V_SC1) v = p.sh3[i - V_SH3];
+        else if (C1 && i < V_SH1) v = p.sc1[i - V_SC1];
+        else if (C1 && i < V_SH1 + C1) v = p.sh1[i - V_SH1];
+        vec[i] = v;
+    }
+
+    // ---- weight stream --------------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t w2h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2_hi, 0, 64 * 576 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2_lo, 0, 64 * 576 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3_hi, 0, BT_OUT * S3 * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3_lo, 0, BT_OUT * S3 * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1_hi, 0, (C1 ? C1 : 16) * BT_OUT * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1_lo, 0, (C1 ? C1 : 16) * BT_OUT * 2, 0x00020000);
+    const int w_lane = lane * 16;
+    // stage JS of the tile program into ring slot `slot`: this wave moves piece `wave` (16 rows) of each plane
+    auto issue_stage = [&](auto js_tag, int slot) {
+        constexpr int JS = decltype(js_tag)::value;
+        char* const d = ring + slot * BT_STAGE + wave * 1024;
+        if (JS < N2) {
+            const int soff = (wave * 18 + JS) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w2h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w2l, MPX_LDS_PTR(d + 4096), 16, w_lane, soff, 0, 0);
+        } else {
+            constexpr int cc = (JS - N2) / SC, r = (JS - N2) % SC;
+            if (r < S3) {
+                const int soff = ((4 * cc + wave) * S3 + r) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3l, MPX_LDS_PTR(d + 4096), 16, w_lane, soff, 0, 0);
+            } else {
+                constexpr int r1 = r - S3, kk = r1 / (H1 ? H1 : 1), hb = r1 % (H1 ? H1 : 1);
+                const int soff = ((4 * hb + wave) * 8 + 2 * cc + kk) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1l, MPX_LDS_PTR(d + 4096), 16, w_lane, soff, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addressing ----------------------------------------------------------------------------------------------
+    const int a_off = lp * 64 + ((lg ^ (((lane >> 3) & 1) << 1)) << 4);           // weight rows: mpx_conv.h's swizzle
+    int pb_off[2][3];      // patch: byte offset of this lane's pixel fragment b at tap column kx (tap row ky: + ky * 1024)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int row = (2 * wave + b) * 16 + lp + kx;
+            pb_off[b][kx] = row * 64 + ((lg ^ ((((lp + kx) >> 2) & 1) << 1)) << 4);
+        }
+    const int sb_off = lp * 64 + ((lg ^ (((lp >> 3) & 1) << 1)) << 4);             // staging, operand layout: + (b*4 + kk*2 + plane)*1024
+
+    // ---- per-lane geometry of the line-layout passes: unit u = (pixel slot u*8 + lane/8, channels 8*(lane%8) ..) ----------------
+    const int uq = lane & 7;
+    int u_pix[4];          // pixel index within the image of unit u's slot (set per tile), or -1 (dead lane)
+
+    f4 acc1[C1 ? 4 * H1 : 1][2];
+    h8 t2h[2][2], t2l[2][2];       // conv3's B operand: [K step][pixel fragment]
+    h8 x0h[2][2], x0l[2][2];       // DUAL: the block input under the downsample conv, B layout, natural K
+    u4 idh[4], idl[4];             // identity lines of the chunk about to be finished, one per unit
+
+    int sbase = 0;                  // ring slot of step 0 of the current tile
+    // prologue: stages 0, 1, 2
+    issue_stage(std::integral_constant<int, 0>{}, 0);
+    issue_stage(std::integral_constant<int, 1>{}, 1);
+    issue_stage(std::integral_constant<int, 2>{}, 2);
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = v0 + it * G;
+        const int n = t / p.tiles_per_img;
+        const int rt = t - n * p.tiles_per_img;
+        const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
+        const int y0 = ty * BT_TY, x0 = tx * BT_TX;
+        const size_t img_pix = (size_t)n * p.H * p.W;
+        const int img_bytes64 = p.H * p.W * BT_MID * 2;
+
+        // ---- t1 patch: 40 pieces of 16 pixels x 32 channels; this wave moves pieces wave*10 .. wave*10+9 -------------------------
+        {
+            const __amdgpu_buffer_rsrc_t th = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_hi + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t tl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_lo + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
+            const int px = lane >> 2;
+            const int ix = x0 - 1 + px;
+            const int col = ix * BT_MID * 2 + (((lane & 3) ^ (((px >> 2) & 1) << 1)) << 4);
+            const int col_oob = (ix | (p.W - 1 - ix)) & (int)OOB;      // ORed in AFTER the row offset is added (a small negative + row would wrap)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int idx = wave * 10 + i;
+                const int py = idx >> 2, s = (idx >> 1) & 1, plane = idx & 1;
+                const int iy = y0 - 1 + py;
+                const int voff = (col + iy * p.W * BT_MID * 2) | col_oob | ((iy | (p.H - 1 - iy)) & (int)OOB);
+                char* const d = patch + (s * 2 + plane) * BT_BLK + py * 1024;
+                if (plane == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(th, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(tl, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
+            }
+        }
+        // unit geometry, descriptors of the 256-channel planes of this image
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = u * 8 + (lane >> 3);
+            const int pc = slot & 15;
+            u_pix[u] = pc < BT_TX ? (y0 + 2 * wave + (slot >> 4)) * p.W + x0 + pc : -1;
+        }
+        const int img_bytes256 = p.H * p.W * BT_OUT * 2;
+        const __amdgpu_buffer_rsrc_t yh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_hi + img_pix * BT_OUT), 0, img_bytes256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y_lo + img_pix * BT_OUT), 0, img_bytes256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rh_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.r_hi + img_pix * (DUAL ? BT_MID : BT_OUT)), 0, DUAL ? img_bytes64 : img_bytes256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.r_lo + img_pix * (DUAL ? BT_MID : BT_OUT)), 0, DUAL ? img_bytes64 : img_bytes256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z_hi + img_pix * (C1 ? C1 : 1)), 0, p.H * p.W * (C1 ? C1 : 1) * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z_lo + img_pix * (C1 ? C1 : 1)), 0, p.H * p.W * (C1 ? C1 : 1) * 2, 0x00020000);
+
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<0>();                        // the patch (and everything older) has landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // identity lines of chunk c (8 loads): unit u reads channels [64c + 8*uq, +8) of its pixel
+        auto issue_identity = [&](int c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB);
+                idh[u] = __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, c * 128, 2);
+                idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, c * 128, 2);
+            }
+        };
+        // top of step J: its stage has landed for every wave, the slot of step J-1 is free: issue stage J+3 into it
+        auto step_top = [&](auto j_tag) {
+            constexpr int J = decltype(j_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<C::wait_top(J)>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_stage(std::integral_constant<int, (J + 3) % NSTEP>{}, (sbase + J + 3) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_a = [&](int slot, h8 (&ah)[4], h8 (&al)[4]) {
+            const char* s = ring + slot * BT_STAGE + a_off;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ah[a] = *(const h8*)(s + a * 1024);
+                al[a] = *(const h8*)(s + 4096 + a * 1024);
+            }
+        };
+        auto mfma_step = [&](f4 (*acc)[2], const h8 (&ah)[4], const h8 (&al)[4], const h8 (&bh)[2], const h8 (&bl)[2]) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+        };
+
+        // ================= conv2: 18 steps over the resident patch ==========================================================
+        f4 acc2[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc2[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        auto conv2_step = [&](auto j_tag) {
+            constexpr int J = decltype(j_tag)::value;
+            constexpr int tap = J >> 1, s = J & 1, ky = tap / 3, kx = tap % 3;
+            step_top(j_tag);
+            if (DUAL && J == C::JX) {
+                // block input fragments (B layout, natural K): lane (pixel lp, group lg) reads channels [32 kk + 8 lg, +8)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int pc = lp < BT_TX ? lp : BT_TX - 1;                    // dead lanes re-read a live pixel
+                    const int voff = ((y0 + 2 * wave + b) * p.W + x0 + pc) * (BT_MID * 2) + lg * 16;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        x0h[kk][b] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, kk * 64, 0));
+                        x0l[kk][b] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, kk * 64, 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!DUAL && J == N2 - 3) {
+                issue_identity(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            h8 ah[4], al[4], bh[2], bl[2];
+            read_a((sbase + J) & 3, ah, al);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                bh[b] = *(const h8*)(patch + (s * 2 + 0) * BT_BLK + pb_off[b][kx] + ky * 1024);
+                bl[b] = *(const h8*)(patch + (s * 2 + 1) * BT_BLK + pb_off[b][kx] + ky * 1024);
+            }
+            mfma_step(acc2, ah, al, bh, bl);
+        };
+        conv2_step(std::integral_constant<int, 0>{});
+        conv2_step(std::integral_constant<int, 1>{});
+        conv2_step(std::integral_constant<int, 2>{});
+        conv2_step(std::integral_constant<int, 3>{});
+        conv2_step(std::integral_constant<int, 4>{});
+        conv2_step(std::integral_constant<int, 5>{});
+        conv2_step(std::integral_constant<int, 6>{});
+        conv2_step(std::integral_constant<int, 7>{});
+        conv2_step(std::integral_constant<int, 8>{});
+        conv2_step(std::integral_constant<int, 9>{});
+        conv2_step(std::integral_constant<int, 10>{});
+        conv2_step(std::integral_constant<int, 11>{});
+        conv2_step(std::integral_constant<int, 12>{});
+        conv2_step(std::integral_constant<int, 13>{});
+        conv2_step(std::integral_constant<int, 14>{});
+        conv2_step(std::integral_constant<int, 15>{});
+        conv2_step(std::integral_constant<int, 16>{});
+        conv2_step(std::integral_constant<int, 17>{});
+
+        // t2 = relu(acc2 * scale2 + shift2), split; registers 4g..4g+3 of row fragments 2s, 2s+1 are K positions 8g..8g+7 of step s
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int a = 2 * s + half;
+                const f4 sc = *(const f4*)(vec + V_SC2 + a * 16 + 4 * lg);
+                const f4 sh = *(const f4*)(vec + V_SH2 + a * 16 + 4 * lg);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f4 v = acc2[a][b] * sc + sh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        half_t hi, lo;
+                        split_f32(fmaxf(v[j], 0.f), hi, lo);
+                        t2h[s][b][half * 4 + j] = hi;
+                        t2l[s][b][half * 4 + j] = lo;
+                    }
+                }
+            }
+
+        if (C1) {
+#pragma unroll
+            for (int a = 0; a < 4 * H1; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc1[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+
+        // ================= 4 output chunks of 64 channels =======================================================================
+        auto chunk = [&](auto c_tag) {
+            constexpr int c = decltype(c_tag)::value;
+            constexpr int J0 = N2 + c * SC;
+            f4 acc3[4][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc3[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+            auto conv3_step = [&](auto r_tag) {
+                constexpr int r = decltype(r_tag)::value;
+                step_top(std::integral_constant<int, J0 + r>{});
+                h8 ah[4], al[4];
+                read_a((sbase + J0 + r) & 3, ah, al);
+                if constexpr (r < 2) mfma_step(acc3, ah, al, t2h[r], t2l[r]);
+                else mfma_step(acc3, ah, al, x0h[r & 1], x0l[r & 1]);
+            };
+            conv3_step(std::integral_constant<int, 0>{});
+            conv3_step(std::integral_constant<int, 1>{});
+            if (DUAL) {
+                conv3_step(std::integral_constant<int, 2>{});
+                conv3_step(std::integral_constant<int, 3>{});
+            }
+            // ---- chunk epilogue (wave-private) ----
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f4 sc = *(const f4*)(vec + V_SC3 + c * 64 + a * 16 + 4 * lg);
+                const f4 sh = *(const f4*)(vec + V_SH3 + c * 64 + a * 16 + 4 * lg);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) *(f4*)(stg + (b * 16 + lp) * 256 + (((a * 4 + lg) ^ lp) << 4)) = acc3[a][b] * sc + sh;
+            }
+            // one pixel fragment (16 slots = units 2b, 2b+1) at a time: its operand bytes replace its own fp32 bytes only
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f4 v0[2], v1[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int slot = (2 * b + k) * 8 + (lane >> 3);
+                    v0[k] = *(const f4*)(stg + slot * 256 + (((2 * uq) ^ (slot & 15)) << 4));
+                    v1[k] = *(const f4*)(stg + slot * 256 + (((2 * uq + 1) ^ (slot & 15)) << 4));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int u = 2 * b + k;
+                    const int slot = u * 8 + (lane >> 3);
+                    float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+                    if (!DUAL) {
+                        const h8 a8 = __builtin_bit_cast(h8, idh[u]);
+                        const h8 c8 = __builtin_bit_cast(h8, idl[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)a8[j] + (float)c8[j];
+                    }
+                    h8 oh, ol;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        half_t hi, lo;
+                        split_f32(fmaxf(v[j], 0.f), hi, lo);
+                        oh[j] = hi;
+                        ol[j] = lo;
+                    }
+                    const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), yh, voff, c * 128, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff, c * 128, 2);
+                    if (C1) {
+                        // operand layout for conv1': [fragment b][K step uq>>2][plane][16 slots][64 B], chunk uq&3 swizzled by the slot
+                        char* const d = stg + (b * 4 + (uq >> 2) * 2) * 1024 + (slot & 15) * 64 + (((uq & 3) ^ (((slot >> 3) & 1) << 1)) << 4);
+                        *(h8*)d = oh;
+                        *(h8*)(d + 1024) = ol;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (C1) {
+                auto conv1_step = [&](auto r_tag) {
+                    constexpr int r1 = decltype(r_tag)::value;
+                    constexpr int kk = r1 / (H1 ? H1 : 1), hb = r1 % (H1 ? H1 : 1);
+                    step_top(std::integral_constant<int, J0 + S3 + r1>{});
+                    if (!DUAL && r1 == 0 && c < 3) {
+                        issue_identity(c + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    h8 ah[4], al[4], bh[2], bl[2];
+                    read_a((sbase + J0 + S3 + r1) & 3, ah, al);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        bh[b] = *(const h8*)(stg + (b * 4 + kk * 2 + 0) * 1024 + sb_off);
+                        bl[b] = *(const h8*)(stg + (b * 4 + kk * 2 + 1) * 1024 + sb_off);
+                    }
+                    mfma_step(&acc1[hb * 4], ah, al, bh, bl);
+                };
+                conv1_step(std::integral_constant<int, 0>{});
+                conv1_step(std::integral_constant<int, 1>{});
+                if (H1 == 2) {
+                    conv1_step(std::integral_constant<int, 2>{});
+                    conv1_step(std::integral_constant<int, 3>{});
+                }
+            }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+
+        // ================= t1' = relu(acc1 * scale1 + shift1) ======================================================================
+        if (C1) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hb = 0; hb < H1; ++hb) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f4 sc = *(const f4*)(vec + V_SC1 + hb * 64 + a * 16 + 4 * lg);
+                    const f4 sh = *(const f4*)(vec + V_SH1 + hb * 64 + a * 16 + 4 * lg);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) *(f4*)(stg + (b * 16 + lp) * 256 + (((a * 4 + lg) ^ lp) << 4)) = acc1[hb * 4 + a][b] * sc + sh;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int slot = u * 8 + (lane >> 3);
+                    const f4 w0 = *(const f4*)(stg + slot * 256 + (((2 * uq) ^ (slot & 15)) << 4));
+                    const f4 w1 = *(const f4*)(stg + slot * 256 + (((2 * uq + 1) ^ (slot & 15)) << 4));
+                    const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    h8 oh, ol;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        half_t hi, lo;
+                        split_f32(fmaxf(v[j], 0.f), hi, lo);
+                        oh[j] = hi;
+                        ol[j] = lo;
+                    }
+                    const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), zh, voff, hb * 128, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), zl, voff, hb * 128, 2);
+                }
+            }
+        }
+        // every wave is done with its staging area (= the patch bytes) before the next tile's patch lands
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        sbase = (sbase + NSTEP) & 3;
+    }
+    wait_vmcnt<0>();
+#endif
+}
+
+typedef BtCfg<false, 64> BtResC64;      // layer1.1 / layer1.2 tails: identity = the trunk, next conv1 256 -> 64
+typedef BtCfg<false, 128> BtResC128;    // layer1's last block: next conv1 = layer2.0.conv1, 256 -> 128
+typedef BtCfg<true, 64> BtDualC64;      // layer1.0: downsample branch K-concatenated, next conv1 256 -> 64
+
+}  // namespace mpx

@@ -343,10 +343,22 @@ class MaskedForwardEngine:
         _lib.check(self._h, self._lib.mpx_set_conv_tile(self._h, int(i), int(tile)), "mpx_set_conv_tile")
 
     def set_fusion(self, on=True):
-        """mpx_forward runs the first bottleneck's conv3 and its downsample conv as one K-concatenated launch, and the ImageNet
-        stem conv with its max pool as one launch (defaults); off = separate launches (the downsample fusion changes the summation
-        order: bit-different results inside the same tolerance; the stem fusion is bit-identical; for tests and ablation)."""
-        _lib.check(self._h, self._lib.mpx_set_fusion(self._h, 1 if on else 0), "mpx_set_fusion")
+        """mpx_set_fusion.  True (default state) = every fusion: a stage's first conv3 with its downsample conv as one
+        K-concatenated launch, the ImageNet stem with its max pool, and layer1's block tails (conv2 -> conv3 + identity -> the
+        next block's conv1, mpx_bottleneck_tail).  False = one launch per layer.  An int is passed through as the mask
+        (1 = round 2's fusions without the block tails).  The stem fusion is bit-identical to the separate launches; the other
+        two change the fp32 summation order (same tolerance)."""
+        mask = (3 if on else 0) if isinstance(on, bool) else int(on)
+        _lib.check(self._h, self._lib.mpx_set_fusion(self._h, mask), "mpx_set_fusion")
+
+    def bottleneck_tails(self):
+        """[(conv2, conv3, downsample or -1, next conv1)] layer indices of the blocks whose tail runs as one launch."""
+        out = []
+        for k in range(self._lib.mpx_num_bottleneck_tails(self._h)):
+            v = [C.c_int() for _ in range(4)]
+            _lib.check(self._h, self._lib.mpx_bottleneck_tail_info(self._h, k, *[C.byref(x) for x in v]), "mpx_bottleneck_tail_info")
+            out.append(tuple(int(x.value) for x in v))
+        return out
 
     def conv_tile(self, layer):
         i = layer if isinstance(layer, int) else [d.name.decode() for d in self.layers].index(layer)

@@ -301,6 +301,90 @@ def test_conv_with_fused_downsample(eng101, stage, tile):
     assert eng101._lib.mpx_conv_dual_bn_act(eng101._h, i + 1, _p(th), _p(tl), _p(xh), _p(xl), _p(oh), _p(ol), batch, None) == -1
 
 
+def _bn_fp64(sd, d, y):
+    bn = d.bn_name.decode()
+    sc = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+    return (y - sd[bn + ".running_mean"].double().view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + sd[bn + ".bias"].double().view(1, -1, 1, 1)
+
+
+def _conv_bn_fp64(sd, d, x_nchw):
+    return _bn_fp64(sd, d, F.conv2d(x_nchw, sd[d.name.decode() + ".weight"].double(), None, d.stride, d.pad))
+
+
+def _round_split(x64):
+    """What a tensor becomes when it is stored as hi + lo fp16 planes (from its fp32 value)."""
+    hi, lo = split(x64.float())
+    return merge(hi, lo).double()
+
+
+@pytest.mark.parametrize("k,batch", [(0, 2), (1, 1), (1, 3), (2, 2), (1, 41), (0, 23), (2, 37)])
+def test_bottleneck_tail_vs_fp64_chain(eng101, k, batch):
+    """mpx_bottleneck_tail (csrc/mpx_btail.h): conv2 -> conv3 + identity (k = 0: + the K-concatenated downsample branch) -> the next
+    block's conv1 (k = 2: layer2.0.conv1, 128 channels) in ONE launch, against the fp64 chain of the same three (four) layers on
+    the same split inputs, with t2 and the block output rounded to hi + lo where the layer-by-layer path stores them.  One image
+    is 28 tiles; 23 .. 41 images are 644 .. 1148 tiles on 512 resident workgroups: tile boundaries, the weight ring running on
+    across tiles, workgroups with one, two and three tiles."""
+    sd = synth.make_state_dict("resnet101")
+    tails = eng101.bottleneck_tails()
+    assert len(tails) == 3
+    c2, c3, ds, n1 = tails[k]
+    d2, d3, dn = eng101.layers[c2], eng101.layers[c3], eng101.layers[n1]
+    assert d2.name.decode() == "layer1.%d.conv2" % k and (ds >= 0) == (k == 0) and dn.cout == (128 if k == 2 else 64)
+    g = torch.Generator().manual_seed(500 + 10 * k + batch)
+    t1 = torch.randn(batch, 56, 56, 64, generator=g).clamp_min(0) * 1.5
+    xc = 64 if ds >= 0 else 256
+    x = torch.randn(batch, 56, 56, xc, generator=g).clamp_min(0) * 1.5
+    dev = eng101.device
+    th, tl = split(t1.to(dev))
+    xh, xl = split(x.to(dev))
+    nan = lambda c: torch.full((batch + 1, 56, 56, c), float("nan"), dtype=torch.float16, device=dev)
+    oh, ol, zh, zl = nan(256), nan(256), nan(dn.cout), nan(dn.cout)
+    rc = eng101._lib.mpx_bottleneck_tail(eng101._h, c2, _p(th), _p(tl), _p(xh), _p(xl), _p(oh), _p(ol), _p(zh), _p(zl), batch, eng101._stream())
+    _lib.check(eng101._h, rc, "mpx_bottleneck_tail")
+    torch.cuda.synchronize()
+    assert torch.isnan(oh[batch]).all() and torch.isnan(zl[batch]).all()           # nothing written past the batch
+
+    t1u, xu = merge(th, tl).cpu().double().permute(0, 3, 1, 2), merge(xh, xl).cpu().double().permute(0, 3, 1, 2)
+    t2 = _round_split(F.relu(_conv_bn_fp64(sd, d2, t1u)))
+    ident = _conv_bn_fp64(sd, eng101.layers[ds], xu) if ds >= 0 else xu
+    out = F.relu(_conv_bn_fp64(sd, d3, t2) + ident)
+    z = F.relu(_conv_bn_fp64(sd, dn, _round_split(out)))
+    got_out = merge(oh[:batch], ol[:batch]).cpu().double().permute(0, 3, 1, 2)
+    got_z = merge(zh[:batch], zl[:batch]).cpu().double().permute(0, 3, 1, 2)
+    assert not torch.isnan(got_out).any() and not torch.isnan(got_z).any()
+    e_out = (got_out - out).abs().max().item() / max(out.abs().max().item(), 1.0)
+    e_z = (got_z - z).abs().max().item() / max(z.abs().max().item(), 1.0)
+    assert e_out <= 4e-6 and e_z <= 4e-6, "tail %d batch %d: out %.3e, next conv1 %.3e" % (k, batch, e_out, e_z)
+
+
+def test_bottleneck_tail_argument_errors(eng101, eng18, dev):
+    t = torch.zeros(8, dtype=torch.float16, device=dev)
+    lib, h = eng101._lib, eng101._h
+    c2 = eng101.bottleneck_tails()[1][0]
+    assert lib.mpx_bottleneck_tail(h, c2 + 1, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 1, None) == -1     # not a conv2 of a tail
+    assert lib.mpx_bottleneck_tail(h, c2, _p(t), _p(t), _p(t), None, _p(t), _p(t), _p(t), _p(t), 1, None) == -1
+    assert lib.mpx_bottleneck_tail(h, c2, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 0, None) == -1
+    assert b"bottleneck_tail" in lib.mpx_last_error(h)
+    assert eng18.bottleneck_tails() == []              # basic blocks have no such tail
+    assert lib.mpx_bottleneck_tail_info(h, 3, None, None, None, None) == -1
+
+
+def test_forward_block_tails_vs_layer_by_layer(eng101):
+    """The same masks with layer1's block tails as single launches (default) and with round 2's launch plan (mask 1): two summation
+    orders of the same arithmetic -- the scores agree to rounding, not bit for bit."""
+    img = synth.make_images(1, seed=9, kind="noise")[0]
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(24, 196, seed=6)
+    _o, s_bt, p_bt = eng101.score_masks(img, seg, onoff, 17)
+    eng101.set_fusion(1)
+    try:
+        _o, s_plain, p_plain = eng101.score_masks(img, seg, onoff, 17)
+    finally:
+        eng101.set_fusion(True)
+    assert np.abs(s_bt - s_plain).max() <= 2e-6 and (p_bt == p_plain).all()
+    assert not (s_bt == s_plain).all()
+
+
 def test_forward_fused_vs_unfused_downsample(eng101):
     """The same masks with the downsample fusion on (default) and off: two different summation orders of the same
     arithmetic, so the scores agree to rounding, not bit for bit."""
