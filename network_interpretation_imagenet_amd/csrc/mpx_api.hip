@@ -843,6 +843,9 @@ int launch_btail(mpx_engine* h, int ti, const half_t* t_hi, const half_t* t_lo, 
     const long long n_tiles = (long long)B * p.tiles_per_img;
     if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) return fail(h, MPX_E_ARG, "block tail: batch out of range");
     p.n_tiles = (int)n_tiles;
+#ifdef MPX_DIAG
+    p.stamps = h->stamps;
+#endif
     const long long resident = 2LL * h->num_cus;                       // two 80-KB workgroups per CU
     const unsigned grid = (unsigned)std::min<long long>(resident / 8 * 8, (n_tiles + 7) / 8 * 8);
     ProfScope ps(h, st, OP_CONV, tb.c2);

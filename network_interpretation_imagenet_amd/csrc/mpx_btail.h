@@ -63,7 +63,30 @@ struct BtParams {
     int tiles_x;             // W / 14
     int tiles_per_img;       // (H / 8) * (W / 14)
     int n_tiles;             // B * tiles_per_img
+#ifdef MPX_DIAG
+    unsigned long long* stamps;   // diagnostic build only (tools/probes/btail_phases.py): 8 u64 per workgroup
+#endif
 };
+
+// Diagnostic build: wave 0 adds up, over the tiles of its workgroup, the s_memtime cycles of each phase.
+#ifdef MPX_DIAG
+#define BT_PHASE(acc)                                                       \
+    do {                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+        (acc) += now_ - bt_last;                                            \
+        bt_last = now_;                                                     \
+    } while (0)
+// finer: inside step_top -- [0] work since the last step_top, [1] counted vmcnt wait, [2] barrier, [3] stage DMA issue
+#define BT_SUB(i)                                                           \
+    do {                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+        bt_sub[i] += now_ - bt_sub_last;                                    \
+        bt_sub_last = now_;                                                 \
+    } while (0)
+#else
+#define BT_PHASE(acc)
+#define BT_SUB(i)
+#endif
 
 constexpr int BT_TY = 8, BT_TX = 14;                    // output pixels of a tile: rows x columns
 constexpr int BT_PY = BT_TY + 2;                        // patch rows; a patch row is 16 pixels (columns -1 .. 14 of the tile)
@@ -91,7 +114,8 @@ struct BtCfg {
     static constexpr int NVEC = 2 * (BT_MID + BT_OUT + (C1 ? C1 : 4));    // floats: sc2 sh2 sc3 sh3 sc1 sh1
     static constexpr int LDS = BT_OFF_RING + BT_NRING * BT_STAGE;
     static_assert(NVEC * 4 <= BT_OFF_PATCH, "vectors overflow their LDS area");
-    static_assert(C1 == 0 || C1 == 64 || C1 == 128, "conv1' has 0, 64 or 128 output channels");
+    static_assert(C1 == 64 || C1 == 128, "conv1' has 64 or 128 output channels");
+    static_assert(NSTEP % 2 == 0, "fragment double buffer: steps alternate parity across tiles");
 
     // ---- the vector-memory program of one tile, per wave (see the header) ----
     static constexpr int mod(int j) { return ((j % NSTEP) + NSTEP) % NSTEP; }
@@ -101,7 +125,8 @@ struct BtCfg {
         if (DUAL) return j == JX ? 8 : 0;
         if (j == N2 - 3) return 8;                                          // identity lines of chunk 0
         for (int c = 1; c < 4; ++c)
-            if (j == N2 + (c - 1) * SC + S3) return 8;                      // ... of chunk c, in the first conv1' step of chunk c-1
+            if (j == N2 + (c - 1) * SC + S3 + (H1 == 2 ? S1 - 1 : 0)) return 8;   // ... of chunk c: in the first (C1 = 128: last,
+                                                                            // the registers are short) conv1' step of chunk c-1
         return 0;
     }
     static constexpr int post(int j) {                  // stores at the end of step j
@@ -113,9 +138,31 @@ struct BtCfg {
         return n;
     }
     static constexpr int all(int j) { return 2 + pre(j) + post(j); }
+    // C1 = 128 is short of registers across a chunk epilogue: the last conv3 step of a chunk does not read the next step's weight
+    // fragments ahead; they are read behind the epilogue instead (their stage has landed by then either way)
+    static constexpr bool late_a(int j) {
+        if (H1 != 2) return false;
+        for (int c = 0; c < 4; ++c)
+            if (j == N2 + c * SC + S3 - 1) return true;
+        return false;
+    }
     // top of step j: the stage of step j (issued first thing in step j-3) has landed; everything behind it may be in flight
     static constexpr int wait_top(int j) { return pre(j - 3) + post(j - 3) + all(j - 2) + all(j - 1); }
 };
+
+// relu, then hi = fp16(v), lo = fp16(v - hi) for 8 values.  `one` is 1.0f in a register the optimiser cannot see through, so that
+// v - (float)hi stays fma((float)hi, -one, v) and becomes ONE v_fma_mix_f32 (fp16 operand converted in the instruction) instead of a
+// conversion and a subtraction: the epilogues of this kernel are VALU-bound.  Same values as split_f32 (fma(h, -1, v) = v - h exactly
+// rounded once).
+__device__ __forceinline__ void bt_relu_split8(const float (&v)[8], float one, h8& oh, h8& ol) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = fmaxf(v[j], 0.f);
+        const half_t hi = (half_t)r;
+        oh[j] = hi;
+        ol[j] = (half_t)__builtin_fmaf((float)hi, -one, r);
+    }
+}
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
@@ -130,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, lg = lane >> 4;
+    float one = 1.0f;
+    asm volatile("" : "+s"(one));       // opaque 1.0 (bt_relu_split8)
 
     // tiles of this workgroup: blocks of one XCD (b % 8) walk neighbouring tiles (shared halo rows stay in that XCD's L2)
     const int G = gridDim.x;                                            // a multiple of 8 (host)
@@ -207,12 +256,52 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     h8 t2h[2][2], t2l[2][2];       // conv3's B operand: [K step][pixel fragment]
     h8 x0h[2][2], x0l[2][2];       // DUAL: the block input under the downsample conv, B layout, natural K
     u4 idh[4], idl[4];             // identity lines of the chunk about to be finished, one per unit
+    struct FragA { h8 hi[4], lo[4]; };
+    struct FragB { h8 hi[2], lo[2]; };
+    FragA fa[2];                   // weight fragments of the current / next step (index = step parity; NSTEP is even)
+    FragB fb[2];                   // conv2: patch fragments, likewise
+    FragB cb[2];                   // conv1': fragments of the chunk's two K steps, from the staging area
 
+#ifdef MPX_DIAG
+    unsigned long long bt_ph[6] = {0, 0, 0, 0, 0, 0};      // patch wait, conv2, conv3 steps, chunk epilogues, conv1' steps, t1' epilogue + end barrier
+    const unsigned long long bt_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long bt_last = bt_t0;
+    unsigned long long bt_sub[5] = {0, 0, 0, 0, 0}, bt_sub_last = bt_t0;
+#endif
     int sbase = 0;                  // ring slot of step 0 of the current tile
-    // prologue: stages 0, 1, 2
+    // prologue: stages 0 .. 3
     issue_stage(std::integral_constant<int, 0>{}, 0);
     issue_stage(std::integral_constant<int, 1>{}, 1);
     issue_stage(std::integral_constant<int, 2>{}, 2);
+    issue_stage(std::integral_constant<int, 3>{}, 3);
+
+    // t1 patch of this workgroup's tile `it`: 40 pieces of 16 pixels x 32 channels; this wave moves pieces wave*10 .. wave*10+9
+    auto issue_patch = [&](int it) {
+        const int t = v0 + it * G;
+        const int n = t / p.tiles_per_img;
+        const int rt = t - n * p.tiles_per_img;
+        const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
+        const int y0 = ty * BT_TY, x0 = tx * BT_TX;
+        const size_t img_pix = (size_t)n * p.H * p.W;
+        const int img_bytes64 = p.H * p.W * BT_MID * 2;
+        const __amdgpu_buffer_rsrc_t th = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_hi + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
+        const __amdgpu_buffer_rsrc_t tl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_lo + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
+        const int px = lane >> 2;
+        const int ix = x0 - 1 + px;
+        const int col = ix * BT_MID * 2 + (((lane & 3) ^ (((px >> 2) & 1) << 1)) << 4);
+        const int col_oob = (ix | (p.W - 1 - ix)) & (int)OOB;      // ORed in AFTER the row offset is added (a small negative + row would wrap)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int idx = wave * 10 + i;
+            const int py = idx >> 2, s = (idx >> 1) & 1, plane = idx & 1;
+            const int iy = y0 - 1 + py;
+            const int voff = (col + iy * p.W * BT_MID * 2) | col_oob | ((iy | (p.H - 1 - iy)) & (int)OOB);
+            char* const d = patch + (s * 2 + plane) * BT_BLK + py * 1024;
+            if (plane == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(th, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(tl, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
+        }
+    };
+    issue_patch(0);
 
     for (int it = 0; it < my_tiles; ++it) {
         const int t = v0 + it * G;
@@ -222,26 +311,6 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         const int y0 = ty * BT_TY, x0 = tx * BT_TX;
         const size_t img_pix = (size_t)n * p.H * p.W;
         const int img_bytes64 = p.H * p.W * BT_MID * 2;
-
-        // ---- t1 patch: 40 pieces of 16 pixels x 32 channels; this wave moves pieces wave*10 .. wave*10+9 -------------------------
-        {
-            const __amdgpu_buffer_rsrc_t th = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_hi + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
-            const __amdgpu_buffer_rsrc_t tl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t_lo + img_pix * BT_MID), 0, img_bytes64, 0x00020000);
-            const int px = lane >> 2;
-            const int ix = x0 - 1 + px;
-            const int col = ix * BT_MID * 2 + (((lane & 3) ^ (((px >> 2) & 1) << 1)) << 4);
-            const int col_oob = (ix | (p.W - 1 - ix)) & (int)OOB;      // ORed in AFTER the row offset is added (a small negative + row would wrap)
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int idx = wave * 10 + i;
-                const int py = idx >> 2, s = (idx >> 1) & 1, plane = idx & 1;
-                const int iy = y0 - 1 + py;
-                const int voff = (col + iy * p.W * BT_MID * 2) | col_oob | ((iy | (p.H - 1 - iy)) & (int)OOB);
-                char* const d = patch + (s * 2 + plane) * BT_BLK + py * 1024;
-                if (plane == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(th, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(tl, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
-            }
-        }
         // unit geometry, descriptors of the 256-channel planes of this image
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -258,9 +327,12 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         const __amdgpu_buffer_rsrc_t zl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z_lo + img_pix * (C1 ? C1 : 1)), 0, p.H * p.W * (C1 ? C1 : 1) * 2, 0x00020000);
 
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<0>();                        // the patch (and everything older) has landed
+        // the patch (and everything older) has landed; behind it only the previous tile's last 8 stores may be in flight
+        if (it == 0) wait_vmcnt<0>();
+        else wait_vmcnt<8>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        BT_PHASE(bt_ph[0]);
 
         // identity lines of chunk c (8 loads): unit u reads channels [64c + 8*uq, +8) of its pixel
         auto issue_identity = [&](int c) {
@@ -271,35 +343,87 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                 idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, c * 128, 2);
             }
         };
-        // top of step J: its stage has landed for every wave, the slot of step J-1 is free: issue stage J+3 into it
-        auto step_top = [&](auto j_tag) {
+        auto read_a1 = [&](int slot, FragA& f, int i) {        // fragment read i = 0..7 of a stage: hi rows 0..3, lo rows 0..3
+            const char* s = ring + slot * BT_STAGE + a_off + (i & 3) * 1024;
+            if (i < 4) f.hi[i] = *(const h8*)s;
+            else f.lo[i - 4] = *(const h8*)(s + 4096);
+        };
+        auto read_patch1 = [&](auto j_tag, FragB& f, int i) {  // fragment read i = 0..3 of conv2 step J: hi b0, hi b1, lo b0, lo b1
             constexpr int J = decltype(j_tag)::value;
+            constexpr int tap = J >> 1, s = J & 1, ky = tap / 3, kx = tap % 3;
+            const char* q = patch + (s * 2 + (i >> 1)) * BT_BLK + pb_off[i & 1][kx] + ky * 1024;
+            if (i < 2) f.hi[i] = *(const h8*)q;
+            else f.lo[i - 2] = *(const h8*)q;
+        };
+        // Step J: MFMAs on the A fragments fa[J & 1] (read during step J-1) and the given B operand, while the fragments of step J+1
+        // are read (its stage has landed: the counted wait + barrier at the top), stage J+4 is issued into the slot of stage J
+        // (every wave finished reading it before the barrier) and, in some steps, the identity lines of a later chunk are requested.
+        auto step = [&](auto j_tag, f4 (*acc)[2], const h8 (&bh)[2], const h8 (&bl)[2]) {
+            constexpr int J = decltype(j_tag)::value;
+            const FragA& A = fa[J & 1];
+            FragA& An = fa[(J + 1) & 1];
             __builtin_amdgcn_sched_barrier(0);
+            BT_SUB(0);
             wait_vmcnt<C::wait_top(J)>();
+            BT_SUB(1);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            issue_stage(std::integral_constant<int, (J + 3) % NSTEP>{}, (sbase + J + 3) & 3);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto read_a = [&](int slot, h8 (&ah)[4], h8 (&al)[4]) {
-            const char* s = ring + slot * BT_STAGE + a_off;
+            BT_SUB(2);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ah[a] = *(const h8*)(s + a * 1024);
-                al[a] = *(const h8*)(s + 4096 + a * 1024);
+            for (int i = 0; i < 24; ++i) {
+                const int a = i / 6, r = i % 6, term = r >> 1, b = r & 1;
+                if (term == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], bl[b], acc[a][b], 0, 0, 0);
+                else if (term == 1) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo[a], bh[b], acc[a][b], 0, 0, 0);
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], bh[b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((i & 1) == 0 && i < 16 && !C::late_a(J)) {
+                    read_a1((sbase + J + 1) & 3, An, i >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((i & 1) == 0 && i >= 16 && J + 1 < N2) {
+                    read_patch1(std::integral_constant<int, (J + 1 < N2 ? J + 1 : 0)>{}, fb[(J + 1) & 1], (i - 16) >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((i & 1) == 0 && i >= 16 && J >= N2 && (J - N2) % SC == S3 + H1 - 1) {
+                    // the step before conv1's second K step of this chunk: its B fragments (written by the chunk epilogue)
+                    const int q = (i - 16) >> 1, b = q & 1, plane = q >> 1;
+                    const h8 f = *(const h8*)(stg + (b * 4 + 2 + plane) * 1024 + sb_off);
+                    if (plane == 0) cb[1].hi[b] = f;
+                    else cb[1].lo[b] = f;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == 1) {
+                    issue_stage(std::integral_constant<int, (J + 4) % NSTEP>{}, (sbase + J) & 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == 5 && C::pre(J)) {
+                    if (DUAL) {
+                        // block input fragments (B layout, natural K): lane (pixel lp, group lg) reads channels [32 kk + 8 lg, +8)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const int pc = lp < BT_TX ? lp : BT_TX - 1;            // dead lanes re-read a live pixel
+                            const int voff = ((y0 + 2 * wave + bb) * p.W + x0 + pc) * (BT_MID * 2) + lg * 16;
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) {
+                                x0h[kk][bb] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, kk * 64, 0));
+                                x0l[kk][bb] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, kk * 64, 0));
+                            }
+                        }
+                    } else {
+                        issue_identity(J < N2 ? 0 : (J - N2) / SC + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
-        auto mfma_step = [&](f4 (*acc)[2], const h8 (&ah)[4], const h8 (&al)[4], const h8 (&bh)[2], const h8 (&bl)[2]) {
+
+        // first fragments of the tile: the patch has landed; the A fragments of step 0 were read during the previous tile's last step
+        if (it == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int i = 0; i < 8; ++i) read_a1(sbase & 3, fa[0], i);
+        }
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-            }
-        };
+        for (int i = 0; i < 4; ++i) read_patch1(std::integral_constant<int, 0>{}, fb[0], i);
 
         // ================= conv2: 18 steps over the resident patch ==========================================================
         f4 acc2[4][2];
@@ -309,34 +433,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
             for (int b = 0; b < 2; ++b) acc2[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
         auto conv2_step = [&](auto j_tag) {
             constexpr int J = decltype(j_tag)::value;
-            constexpr int tap = J >> 1, s = J & 1, ky = tap / 3, kx = tap % 3;
-            step_top(j_tag);
-            if (DUAL && J == C::JX) {
-                // block input fragments (B layout, natural K): lane (pixel lp, group lg) reads channels [32 kk + 8 lg, +8)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int pc = lp < BT_TX ? lp : BT_TX - 1;                    // dead lanes re-read a live pixel
-                    const int voff = ((y0 + 2 * wave + b) * p.W + x0 + pc) * (BT_MID * 2) + lg * 16;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        x0h[kk][b] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, kk * 64, 0));
-                        x0l[kk][b] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, kk * 64, 0));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!DUAL && J == N2 - 3) {
-                issue_identity(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            h8 ah[4], al[4], bh[2], bl[2];
-            read_a((sbase + J) & 3, ah, al);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                bh[b] = *(const h8*)(patch + (s * 2 + 0) * BT_BLK + pb_off[b][kx] + ky * 1024);
-                bl[b] = *(const h8*)(patch + (s * 2 + 1) * BT_BLK + pb_off[b][kx] + ky * 1024);
-            }
-            mfma_step(acc2, ah, al, bh, bl);
+            step(j_tag, acc2, fb[J & 1].hi, fb[J & 1].lo);
         };
         conv2_step(std::integral_constant<int, 0>{});
         conv2_step(std::integral_constant<int, 1>{});
@@ -356,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         conv2_step(std::integral_constant<int, 15>{});
         conv2_step(std::integral_constant<int, 16>{});
         conv2_step(std::integral_constant<int, 17>{});
+        BT_PHASE(bt_ph[1]);
 
         // t2 = relu(acc2 * scale2 + shift2), split; registers 4g..4g+3 of row fragments 2s, 2s+1 are K positions 8g..8g+7 of step s
 #pragma unroll
@@ -370,20 +468,18 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                     const f4 v = acc2[a][b] * sc + sh;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        half_t hi, lo;
-                        split_f32(fmaxf(v[j], 0.f), hi, lo);
+                        const float r = fmaxf(v[j], 0.f);
+                        const half_t hi = (half_t)r;
                         t2h[s][b][half * 4 + j] = hi;
-                        t2l[s][b][half * 4 + j] = lo;
+                        t2l[s][b][half * 4 + j] = (half_t)__builtin_fmaf((float)hi, -one, r);
                     }
                 }
             }
 
-        if (C1) {
 #pragma unroll
-            for (int a = 0; a < 4 * H1; ++a)
+        for (int a = 0; a < 4 * H1; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc1[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-        }
+            for (int b = 0; b < 2; ++b) acc1[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
         // ================= 4 output chunks of 64 channels =======================================================================
         auto chunk = [&](auto c_tag) {
@@ -394,22 +490,15 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc3[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-            auto conv3_step = [&](auto r_tag) {
-                constexpr int r = decltype(r_tag)::value;
-                step_top(std::integral_constant<int, J0 + r>{});
-                h8 ah[4], al[4];
-                read_a((sbase + J0 + r) & 3, ah, al);
-                if constexpr (r < 2) mfma_step(acc3, ah, al, t2h[r], t2l[r]);
-                else mfma_step(acc3, ah, al, x0h[r & 1], x0l[r & 1]);
-            };
-            conv3_step(std::integral_constant<int, 0>{});
-            conv3_step(std::integral_constant<int, 1>{});
-            if (DUAL) {
-                conv3_step(std::integral_constant<int, 2>{});
-                conv3_step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, J0>{}, acc3, t2h[0], t2l[0]);
+            step(std::integral_constant<int, J0 + 1>{}, acc3, t2h[1], t2l[1]);
+            if constexpr (DUAL) {
+                step(std::integral_constant<int, J0 + 2>{}, acc3, x0h[0], x0l[0]);
+                step(std::integral_constant<int, J0 + 3>{}, acc3, x0h[1], x0l[1]);
             }
             // ---- chunk epilogue (wave-private) ----
             __builtin_amdgcn_sched_barrier(0);
+            BT_PHASE(bt_ph[2]);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const f4 sc = *(const f4*)(vec + V_SC3 + c * 64 + a * 16 + 4 * lg);
@@ -433,56 +522,45 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                     const int slot = u * 8 + (lane >> 3);
                     float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
                     if (!DUAL) {
+                        // + identity (hi + lo): two v_fma_mix_f32 per element (the fp16 -> fp32 conversions ride in the instruction)
                         const h8 a8 = __builtin_bit_cast(h8, idh[u]);
                         const h8 c8 = __builtin_bit_cast(h8, idl[u]);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)a8[j] + (float)c8[j];
+                        for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf((float)c8[j], one, __builtin_fmaf((float)a8[j], one, v[j]));
                     }
                     h8 oh, ol;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        half_t hi, lo;
-                        split_f32(fmaxf(v[j], 0.f), hi, lo);
-                        oh[j] = hi;
-                        ol[j] = lo;
-                    }
+                    bt_relu_split8(v, one, oh, ol);
                     const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), yh, voff, c * 128, 2);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff, c * 128, 2);
-                    if (C1) {
-                        // operand layout for conv1': [fragment b][K step uq>>2][plane][16 slots][64 B], chunk uq&3 swizzled by the slot
-                        char* const d = stg + (b * 4 + (uq >> 2) * 2) * 1024 + (slot & 15) * 64 + (((uq & 3) ^ (((slot >> 3) & 1) << 1)) << 4);
-                        *(h8*)d = oh;
-                        *(h8*)(d + 1024) = ol;
-                    }
+                    // operand layout for conv1': [fragment b][K step uq>>2][plane][16 slots][64 B], chunk uq&3 swizzled by the slot
+                    char* const d = stg + (b * 4 + (uq >> 2) * 2) * 1024 + (slot & 15) * 64 + (((uq & 3) ^ (((slot >> 3) & 1) << 1)) << 4);
+                    *(h8*)d = oh;
+                    *(h8*)(d + 1024) = ol;
                 }
+            }
+            if (C::late_a(J0 + S3 - 1)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) read_a1((sbase + J0 + S3) & 3, fa[(J0 + S3) & 1], i);
+            }
+            // B fragments of conv1's first K step of this chunk (the second one's are read during the step before it)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                cb[0].hi[b] = *(const h8*)(stg + (b * 4 + 0) * 1024 + sb_off);
+                cb[0].lo[b] = *(const h8*)(stg + (b * 4 + 1) * 1024 + sb_off);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (C1) {
-                auto conv1_step = [&](auto r_tag) {
-                    constexpr int r1 = decltype(r_tag)::value;
-                    constexpr int kk = r1 / (H1 ? H1 : 1), hb = r1 % (H1 ? H1 : 1);
-                    step_top(std::integral_constant<int, J0 + S3 + r1>{});
-                    if (!DUAL && r1 == 0 && c < 3) {
-                        issue_identity(c + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    h8 ah[4], al[4], bh[2], bl[2];
-                    read_a((sbase + J0 + S3 + r1) & 3, ah, al);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        bh[b] = *(const h8*)(stg + (b * 4 + kk * 2 + 0) * 1024 + sb_off);
-                        bl[b] = *(const h8*)(stg + (b * 4 + kk * 2 + 1) * 1024 + sb_off);
-                    }
-                    mfma_step(&acc1[hb * 4], ah, al, bh, bl);
-                };
-                conv1_step(std::integral_constant<int, 0>{});
-                conv1_step(std::integral_constant<int, 1>{});
-                if (H1 == 2) {
-                    conv1_step(std::integral_constant<int, 2>{});
-                    conv1_step(std::integral_constant<int, 3>{});
-                }
+            BT_PHASE(bt_ph[3]);
+            // conv1' steps: K step kk = r1 / H1 of this chunk, 64-row block hb = r1 % H1
+            step(std::integral_constant<int, J0 + S3>{}, &acc1[0], cb[0].hi, cb[0].lo);
+            if constexpr (H1 == 1) {
+                step(std::integral_constant<int, J0 + S3 + 1>{}, &acc1[0], cb[1].hi, cb[1].lo);
+            } else {
+                step(std::integral_constant<int, J0 + S3 + 1>{}, &acc1[4], cb[0].hi, cb[0].lo);
+                step(std::integral_constant<int, J0 + S3 + 2>{}, &acc1[0], cb[1].hi, cb[1].lo);
+                step(std::integral_constant<int, J0 + S3 + 3>{}, &acc1[4], cb[1].hi, cb[1].lo);
             }
+            BT_PHASE(bt_ph[4]);
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
@@ -490,45 +568,67 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         chunk(std::integral_constant<int, 3>{});
 
         // ================= t1' = relu(acc1 * scale1 + shift1) ======================================================================
-        if (C1) {
-            __builtin_amdgcn_sched_barrier(0);
+        // The last 8 stores are held back until the next tile's patch has been requested (the staging bytes it lands in are free
+        // once every wave has read its last lines), so that the wait for the patch does not wait for them.
+        __builtin_amdgcn_sched_barrier(0);
+        h8 zoh[4], zol[4];
 #pragma unroll
-            for (int hb = 0; hb < H1; ++hb) {
+        for (int hb = 0; hb < H1; ++hb) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const f4 sc = *(const f4*)(vec + V_SC1 + hb * 64 + a * 16 + 4 * lg);
-                    const f4 sh = *(const f4*)(vec + V_SH1 + hb * 64 + a * 16 + 4 * lg);
+            for (int a = 0; a < 4; ++a) {
+                const f4 sc = *(const f4*)(vec + V_SC1 + hb * 64 + a * 16 + 4 * lg);
+                const f4 sh = *(const f4*)(vec + V_SH1 + hb * 64 + a * 16 + 4 * lg);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) *(f4*)(stg + (b * 16 + lp) * 256 + (((a * 4 + lg) ^ lp) << 4)) = acc1[hb * 4 + a][b] * sc + sh;
-                }
+                for (int b = 0; b < 2; ++b) *(f4*)(stg + (b * 16 + lp) * 256 + (((a * 4 + lg) ^ lp) << 4)) = acc1[hb * 4 + a][b] * sc + sh;
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int slot = u * 8 + (lane >> 3);
-                    const f4 w0 = *(const f4*)(stg + slot * 256 + (((2 * uq) ^ (slot & 15)) << 4));
-                    const f4 w1 = *(const f4*)(stg + slot * 256 + (((2 * uq + 1) ^ (slot & 15)) << 4));
-                    const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-                    h8 oh, ol;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        half_t hi, lo;
-                        split_f32(fmaxf(v[j], 0.f), hi, lo);
-                        oh[j] = hi;
-                        ol[j] = lo;
-                    }
+            for (int u = 0; u < 4; ++u) {
+                const int slot = u * 8 + (lane >> 3);
+                const f4 w0 = *(const f4*)(stg + slot * 256 + (((2 * uq) ^ (slot & 15)) << 4));
+                const f4 w1 = *(const f4*)(stg + slot * 256 + (((2 * uq + 1) ^ (slot & 15)) << 4));
+                const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                bt_relu_split8(v, one, zoh[u], zol[u]);
+                if (hb + 1 < H1) {
                     const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), zh, voff, hb * 128, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), zl, voff, hb * 128, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, hb * 128, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, hb * 128, 2);
                 }
             }
         }
         // every wave is done with its staging area (= the patch bytes) before the next tile's patch lands
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BT_SUB(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        BT_SUB(2);
+        if (it + 1 < my_tiles) issue_patch(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BT_SUB(4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, (H1 - 1) * 128, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, (H1 - 1) * 128, 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        BT_SUB(3);
         sbase = (sbase + NSTEP) & 3;
+        BT_PHASE(bt_ph[5]);
     }
     wait_vmcnt<0>();
+#ifdef MPX_DIAG
+    if (p.stamps && tid == 0) {
+        unsigned long long* o_ = p.stamps + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o_[i] = bt_ph[i];
+        o_[6] = __builtin_amdgcn_s_memtime() - bt_t0;
+        o_[7] = (unsigned long long)my_tiles;
+        unsigned long long* q_ = p.stamps + (size_t)(gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q_[i] = bt_sub[i];
+    }
+#endif
 #endif
 }
 

@@ -20,6 +20,8 @@ dev = torch.device("cuda", 0)
 eng = MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(synth.make_state_dict(arch))
 if os.environ.get("MPX_NO_FUSION"):     # tool-only: run a stage's first conv3 and its downsample conv as two launches
     eng.set_fusion(False)
+if os.environ.get("MPX_FUSION_MASK"):   # tool-only: mpx_set_fusion mask (1 = round 2's plan: no block tails)
+    eng.set_fusion(int(os.environ["MPX_FUSION_MASK"]))
 img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
 seg = torch.from_numpy(synth.grid_segments()).to(dev)
 onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
@@ -85,6 +87,15 @@ print("-- grouped by shape --")
 for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     print("%5d->%-5d k%d s%d out%-4d x%-3d %8.3f ms %5.1f%% %8.1f TFLOP/s%s" % (key[0], key[1], key[2], key[3], key[4], n, ms, 100 * ms / tot, fl / max(ms, 1e-9) / 1e9,
                                                                              "   (runs inside its block's conv3 launch)" if ms == 0 else ""))
+tails = eng.bottleneck_tails()
+if tails and not os.environ.get("MPX_NO_FUSION") and os.environ.get("MPX_FUSION_MASK", "3") == "3":
+    names = [d.name.decode() for d in eng.layers]
+    print("-- block tails (one launch each: conv2 -> conv3 + identity -> next conv1; the time is booked on the conv2 row) --")
+    for c2, c3, ds, n1 in tails:
+        print("  %-16s + %s%s + %-16s %8.3f ms" % (names[c2], names[c3], (" + " + names[ds]) if ds >= 0 else "", names[n1],
+                                                    prof["per_conv_ms"][c2] / reps))
+layer1 = sum(ms for d, ms in zip(eng.layers, prof["per_conv_ms"]) if d.name.startswith(b"layer1.") or d.name == b"layer2.0.conv1") / reps
+print("layer1 (+ layer2.0.conv1): %.3f ms/batch" % layer1)
 allfl = eng.flops_per_forward * batch
 print("conv total %.3f ms/batch -> %.1f TFLOP/s algorithmic; other kinds ms/batch: %s" % (
     tot, allfl / tot / 1e9, {k: round(v / reps, 3) for k, v in prof["ms"].items()}))
