@@ -40,10 +40,6 @@ def parse():
                     help="images whose masks share one forward batch (batch = this x masks; larger batches fill "
                          "256 CUs with fewer partial rounds of tiles)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent forward batches in flight (one engine + HIP stream each): lets the HBM-bound "
-                         "kernels of one batch overlap the MFMA-bound kernels of another")
-    ap.add_argument("--stream-offset", action="store_true", help="with --streams > 1: start the streams out of phase")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
     return ap.parse_args()
@@ -137,10 +133,7 @@ def main():
         raise SystemExit("--images must be a multiple of --images-per-forward")
     batch = ipf * n_mask
     sd = synth.make_state_dict(args.arch)
-    engines = [MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank).load_state_dict(sd)
-               for _ in range(max(1, args.streams))]
-    streams = [torch.cuda.Stream(device=dev) for _ in engines]
-    eng = engines[0]
+    eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank).load_state_dict(sd)
     # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
     # per-image Bernoulli(0.4) mask-vectors, labels = unmasked argmax (the reference's correctness gate)
     imgs = torch.from_numpy(synth.make_images(n_img, seed=1234 + rank, kind="noise")).to(dev)
@@ -160,30 +153,14 @@ def main():
     preds = torch.empty(n_img, n_mask, dtype=torch.int32, device=dev)
     total = world * n_img * n_mask
 
-    def step(profile):
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(dev))
-        if len(engines) > 1 and args.stream_offset:
-            # put stream k a fraction k/n of a forward behind stream 0, so that one stream's HBM-bound layers
-            # meet another's MFMA-bound layers instead of running the same layer side by side
-            for k in range(1, len(engines)):
-                with torch.cuda.stream(streams[k]):
-                    nb = batch * k // len(engines)
-                    engines[k].forward(nb, label_rows[:ipf].view(-1)[:nb].contiguous())
-        for f, i0 in enumerate(range(0, n_img, ipf)):
-            e, st = engines[f % len(engines)], streams[f % len(engines)]
-            prof = profile and e is eng
-            with torch.cuda.stream(st):
-                if prof:
-                    e.profile(True)
-                for j in range(ipf):
-                    e.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
-                e.forward(batch, label_rows[i0:i0 + ipf].view(-1), score_out=scores[i0:i0 + ipf].view(-1),
-                          pred_out=preds[i0:i0 + ipf].view(-1))
-                if prof:
-                    e.profile(False)
-        for st in streams:
-            torch.cuda.current_stream(dev).wait_stream(st)
+    img_list = list(imgs)
+    onoff_list = list(onoff)
+    label_flat = label_rows.view(-1)
+
+    def step():
+        # the product entry (MaskedForwardEngine.score_packed): the mask rows of consecutive images share forward batches of
+        # `batch` slots -- K0 per image, then the network, for every (image, mask) of this rank; allocates and synchronises nothing
+        eng.score_packed(img_list, seg, onoff_list, label_flat, scores.view(-1), preds.view(-1))
         if use_dist:
             return shard.all_gather_blocks(scores.view(-1), total)
         return scores.view(-1)
@@ -194,7 +171,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
     # the timed region: exactly K steps, nothing but the step inside (no per-kernel events, no allocation); ONE pair of
     # HIP events on the launch stream brackets it for the GPU-side time
@@ -202,7 +179,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        out = step(False)
+        out = step()
     ev1.record()
     fence()
     dt = time.perf_counter() - t0
@@ -218,18 +195,12 @@ def main():
     batches_profiled = 0
     if rank == 0:
         step_imgs = min(n_img, 32 * ipf)
-        for f, i0 in enumerate(range(0, step_imgs, ipf)):
-            eng.profile(True)
-            for j in range(ipf):
-                eng.stage_masks(imgs[i0 + j], seg, onoff[i0 + j], j * n_mask)
-            eng.forward(batch, label_rows[i0:i0 + ipf].view(-1), score_out=scores[i0:i0 + ipf].view(-1),
-                        pred_out=preds[i0:i0 + ipf].view(-1))
-            eng.profile(False)
-            part = eng.collect_profile()
-            batches_profiled += 1
-            for key in ("ms", "launches"):
-                for k, v in part[key].items():
-                    prof[key][k] = prof[key].get(k, 0) + v
+        rows = step_imgs * n_mask
+        eng.profile(True)
+        eng.score_packed(img_list[:step_imgs], seg, onoff_list[:step_imgs], label_flat[:rows], scores.view(-1)[:rows], preds.view(-1)[:rows])
+        eng.profile(False)
+        prof = eng.collect_profile()
+        batches_profiled = step_imgs // ipf
         torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -268,15 +239,14 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
-                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "streams": len(engines),
+                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "entry": "MaskedForwardEngine.score_packed",
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline(args.arch, args.cpu_masks) if (world == 1 and args.cpu_masks > 0) else None,
         }
         print(json.dumps(line))
-    for e in engines:
-        e.close()
+    eng.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -22,7 +22,8 @@ from . import masks
 from .engine import BasePredictionWrong, rank_segments, IMG
 
 __all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
-           "validate", "validate_gp_superpixel", "validate_summed", "validate_summed_many", "score_masks", "default_segmenter",
+           "validate", "validate_gp_superpixel", "validate_summed", "validate_summed_many", "validate_many", "fill_tables",
+           "score_masks", "default_segmenter",
            "jet_heatmap_u8",
            "img_show_u8", "load_images_from_folder", "prepare_training_data", "get_pixel_sorted_mask_label",
            "summed_heatmap_from_folder",
@@ -279,13 +280,31 @@ def validate_gp_superpixel(val_loader, model, criterion, eval_img_index, num_mas
 validate_summed = validate_gp_superpixel      # earlier name of the same entry point
 
 
-def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mask_samples=None, rng=None,
-                         workers=4, lookahead=None):
-    """The heat map of validate_gp_superpixel for several images of one pass over the loader: {index: f64[224,224] or None}
-    (None where the unmasked prediction is wrong, the reference's "wrong prediction" branch).
-    The CPU segmentation of the next images (segment.SegmenterPool) runs while the GPU scores the
-    current one -- the reference segments and scores strictly one after the other
-    (gp_superpixel_data_imagenet.py:206-232)."""
+def fill_tables(engine, sessions):
+    """Score the unmasked image and EVERY window start 0..S of several sessions in packed forward batches
+    (MaskedForwardEngine.score_images: the rows of consecutive images share batches of up to max_batch slots) -- one image's
+    table is only S+2 = 50 .. 350 rows, a fraction of the batch the engine is fast at.  Sets each session's base_pred and
+    table; -> [bool]: the unmasked prediction equals the label (the reference's gate, generate_gp_training_data_imagenet.py:215).
+    Scores are bit-identical to SaliencySession.table() one image at a time."""
+    todo = [s for s in sessions if s._table is None or s.base_pred is None]
+    if todo:
+        rows = []
+        for s in todo:
+            onoff = np.empty((s.num_segments + 2, s.num_segments), dtype=np.uint8)
+            onoff[0] = 1                                                    # row 0: the unmasked image
+            onoff[1:] = masks.windows_onoff(s.num_segments, range(0, s.num_segments + 1))
+            rows.append(onoff)
+        res = engine.score_images([s.input for s in todo], [s.seg_rank for s in todo], rows, [s.label for s in todo])
+        for s, (score, pred) in zip(todo, res):
+            s.base_pred = int(pred[0])
+            s._table = (score[1:], pred[1:])
+    return [s.base_pred == s.label for s in sessions]
+
+
+def _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, lookahead, emit):
+    """Common driver of validate_many / validate_summed_many: one pass over the loader; the CPU segmentation of the next
+    images (segment.SegmenterPool) runs while the GPU scores the current group; the tables of consecutive images are packed
+    into full forward batches (fill_tables).  emit(index, session, firsts, correct) -> the per-image result."""
     from collections import deque
     from . import segment
     n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
@@ -296,18 +315,29 @@ def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mas
     lookahead = int(lookahead or 2 * workers)
     rng = rng or (random.Random(_CONFIG["seed"]) if _CONFIG["seed"] is not None else random)
     out = {}
-    pending = deque()
+    pending = deque()       # (index, input, target, future of the label map), loader order
+    group = []              # sessions whose label map is in, waiting for a full batch
+    rows = [0]
 
-    def finish(idx, x, target, fut):
-        try:
-            s = SaliencySession(model, x, target, segments=fut.result())
-        except BasePredictionWrong:
-            out[idx] = None
-            return
-        firsts = masks.draw_first_indices(s.num_segments, n, rng)
-        _score, table_pred = s.table()
-        correct = np.array([table_pred[f] for f in firsts], dtype=np.int64) == s.label
-        out[idx] = s.summed_labels(firsts, correct)
+    def flush():
+        ok = fill_tables(model, [s for _i, s in group])
+        for (idx, s), good in zip(group, ok):
+            if not good:
+                out[idx] = None
+                continue
+            firsts = masks.draw_first_indices(s.num_segments, n, rng)
+            _score, table_pred = s.table()
+            correct = np.array([table_pred[f] for f in firsts], dtype=np.int64) == s.label
+            out[idx] = emit(idx, s, firsts, correct)
+        del group[:]
+        rows[0] = 0
+
+    def segmented(idx, x, target, fut):
+        s = SaliencySession(model, x, target, segments=fut.result(), check_base=False)
+        group.append((idx, s))
+        rows[0] += s.num_segments + 2
+        if rows[0] >= model.max_batch:
+            flush()
 
     with segment.SegmenterPool(workers=workers) as pool:
         count = 0
@@ -322,12 +352,38 @@ def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mas
                     fut = pool.submit(x.numpy())
                 pending.append((count, x, item[1], fut))
                 if len(pending) > lookahead:
-                    finish(*pending.popleft())
+                    segmented(*pending.popleft())
             if count >= max(want):
                 break
         while pending:
-            finish(*pending.popleft())
+            segmented(*pending.popleft())
+        if group:
+            flush()
     return out
+
+
+def validate_summed_many(val_loader, model, criterion, eval_img_indices, num_mask_samples=None, rng=None,
+                         workers=4, lookahead=None):
+    """The heat map of validate_gp_superpixel for several images of one pass over the loader: {index: f64[224,224] or None}
+    (None where the unmasked prediction is wrong, the reference's "wrong prediction" branch).  The reference segments and
+    scores strictly one image and one mask after the other (gp_superpixel_data_imagenet.py:206-232,276-334); here the
+    segmentation of the next images overlaps the GPU and the window tables of consecutive images share full forward batches."""
+    return _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, lookahead,
+                 lambda idx, s, firsts, correct: s.summed_labels(firsts, correct))
+
+
+def validate_many(val_loader, model, criterion, eval_img_indices, num_mask_samples=None, rng=None, workers=4, lookahead=None):
+    """validate() for several images of one pass over the loader: {index: correct_pred_count, or None where the unmasked
+    prediction is wrong} (generate_gp_training_data_imagenet.py:152-273 run once per image, its random window draws included).
+    With configure(mask_dir=...) the PNGs of image `index` go to <mask_dir>/img_<index>/mask_{i}_{label}.png (:260,265)."""
+    def emit(idx, s, firsts, correct):
+        if _CONFIG["mask_dir"]:
+            d = os.path.join(_CONFIG["mask_dir"], "img_%d" % idx)
+            os.makedirs(d, exist_ok=True)
+            for i, (f, ok) in enumerate(zip(firsts, correct)):
+                _write_png(os.path.join(d, "mask_{}_{}.png".format(i, int(ok))), s.mask_u8(f))
+        return int(correct.sum())
+    return _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, lookahead, emit)
 
 
 def load_images_from_folder(folder):

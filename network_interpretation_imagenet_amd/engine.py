@@ -183,17 +183,26 @@ class MaskedForwardEngine:
                                                   int(batch), self._stream()), "mpx_forward")
         return (score, pred, logits[:, :self.num_classes]) if want_logits else (score, pred)
 
+    def input_plane_shape(self, n):
+        """Shape of n slots of the engine's input staging: [n,230,230,4] (padded NHWC4, the 7x7 stem's operand) for the ImageNet
+        ResNets, [n,H,W,32] (channels padded to 32) for the small networks (csrc/mpx_api.hip mpx_create)."""
+        if self.small:
+            return (int(n), self.image_size, self.image_size, 32)
+        return (int(n), _lib.IMG_PAD, _lib.IMG_PAD, 4)
+
     def input_planes(self, n=None):
-        """Zero-copy fp16 views [n,230,230,4] of the engine-owned padded NHWC4 input staging planes
-        (hi, lo).  For tests and diagnostics."""
+        """Zero-copy fp16 views of the engine-owned input staging planes (hi, lo), shaped input_plane_shape(n).
+        For tests and diagnostics."""
         n = self.max_batch if n is None else int(n)
+        if not 0 < n <= self.max_batch:
+            raise ValueError("input_planes: n must be in [1, max_batch=%d]" % self.max_batch)
         hi, lo = C.c_void_p(), C.c_void_p()
         _lib.check(self._h, self._lib.mpx_input_planes(self._h, C.byref(hi), C.byref(lo)), "mpx_input_planes")
+        shape = self.input_plane_shape(n)
 
         class _View:
             def __init__(self, ptr):
-                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n, _lib.IMG_PAD, _lib.IMG_PAD, 4),
-                                                 "typestr": "<f2", "version": 2}
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": "<f2", "version": 2}
 
         return (torch.as_tensor(_View(hi.value), device=self.device),
                 torch.as_tensor(_View(lo.value), device=self.device))
@@ -299,6 +308,79 @@ class MaskedForwardEngine:
             if return_logits:
                 logits[s0:s0 + b] = out[2].cpu().numpy()
         return (onoff, score, pred, logits) if return_logits else (onoff, score, pred)
+
+    def score_packed(self, images, segs, onoffs, label_rows, score_out, pred_out):
+        """Device-resident packed scoring: the mask rows of SEVERAL images share forward batches of up to max_batch slots
+        (an image's rows may straddle two batches), so the network always runs at the batch size it is fast at -- the
+        reference scores one mask per forward (generate_gp_training_data_imagenet.py:240-248,
+        gp_superpixel_data_imagenet.py:299-307).  images: sequence of device tensors (u8[224,224,3] or f32[3,224,224]);
+        segs: ONE device i32[224,224] rank map shared by all images, or a sequence with one per image; onoffs: sequence of
+        device u8[M_i, S_i]; label_rows: device i32[sum M_i] (image i's label repeated M_i times); score_out f32 / pred_out
+        i32 [sum M_i] receive the results.  Allocates nothing, synchronises nothing; results are bit-identical to scoring
+        every image on its own (kernel choice does not depend on where a mask sits in a batch)."""
+        n = len(images)
+        shared = isinstance(segs, torch.Tensor)
+        if len(onoffs) != n or (not shared and len(segs) != n):
+            raise ValueError("images, segs and onoffs must have one entry per image")
+        total = sum(int(o.shape[0]) for o in onoffs)
+        for name, t, dt in (("label_rows", label_rows, torch.int32), ("score_out", score_out, torch.float32), ("pred_out", pred_out, torch.int32)):
+            if t.dtype != dt or t.device != self.device or t.numel() != total or not t.is_contiguous():
+                raise ValueError("%s must be contiguous %s[%d] on %s" % (name, dt, total, self.device))
+        label_rows, score_out, pred_out = label_rows.view(-1), score_out.view(-1), pred_out.view(-1)
+        done = 0            # rows already handed to a forward
+        used = 0            # slots staged for the next forward
+        for i in range(n):
+            m, r = int(onoffs[i].shape[0]), 0
+            seg = segs if shared else segs[i]
+            while r < m:
+                take = min(m - r, self.max_batch - used)
+                self.stage_masks(images[i], seg, onoffs[i][r:r + take], used)
+                used += take
+                r += take
+                if used == self.max_batch:
+                    self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
+                    done += used
+                    used = 0
+        if used:
+            self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
+
+    def score_images(self, images, segments, onoffs, labels):
+        """Host convenience over score_packed: [(image, segments, onoff u8[M_i,S_i], label)] for several images ->
+        [(score f32[M_i], pred i32[M_i])], with ONE upload of the inputs and ONE download of all scores.  `segments` are
+        arbitrary integer label maps (ranked here as score_masks does)."""
+        if self.small:
+            raise ValueError("%s scores with score_masks_removed (the small networks' mask convention)" % self.arch)
+        n = len(images)
+        if not (len(segments) == len(onoffs) == len(labels) == n):
+            raise ValueError("images, segments, onoffs and labels must have the same length")
+        img_d, seg_d, onoff_d, lab, sizes = [], [], [], [], []
+        for i in range(n):
+            seg_rank, s = rank_segments(segments[i])
+            o = np.ascontiguousarray(onoffs[i])
+            if o.dtype != np.uint8 or o.ndim != 2 or o.shape[1] != s:
+                raise ValueError("onoffs[%d] must be uint8[M,%d] (S = number of distinct segment labels), got %s%s" % (i, s, o.dtype, o.shape))
+            if not 0 <= int(labels[i]) < NUM_CLASSES:
+                raise ValueError("label %r outside [0,1000)" % (labels[i],))
+            sizes.append(o.shape[0])
+            if o.shape[0] == 0:
+                continue
+            img_d.append(self._image_to_device(images[i]))
+            seg_d.append(torch.from_numpy(seg_rank).to(self.device))
+            onoff_d.append(torch.from_numpy(o).to(self.device))
+            lab.append(np.full(o.shape[0], int(labels[i]), dtype=np.int32))
+        total = int(sum(sizes))
+        if total == 0:
+            return [(np.empty(0, np.float32), np.empty(0, np.int32)) for _ in range(n)]
+        label_rows = torch.from_numpy(np.concatenate(lab)).to(self.device)
+        score = torch.empty(total, dtype=torch.float32, device=self.device)
+        pred = torch.empty(total, dtype=torch.int32, device=self.device)
+        self.score_packed(img_d, seg_d, onoff_d, label_rows, score, pred)
+        score, pred = score.cpu().numpy(), pred.cpu().numpy()
+        out, at = [], 0
+        for m in sizes:
+            out.append((score[at:at + m].copy(), pred[at:at + m].copy()))
+            at += m
+        return out
 
     def predict(self, image):
         """Unmasked forward: (argmax class, softmax f32[1000])

@@ -401,6 +401,51 @@ def test_forward_fused_vs_unfused_downsample(eng101):
     assert not (s_fused == s_plain).all()          # they really are two code paths
 
 
+@pytest.mark.parametrize("which", ["resnet18", "resnet101"])
+def test_score_images_packed_equals_per_image(eng18, eng101, golden_dir, which):
+    """MaskedForwardEngine.score_images / score_packed: the mask rows of consecutive images share forward batches (rows of one
+    image straddle two batches; images with different label maps, one of them felzenszwalb's; u8 and normalised f32 inputs).
+    The packed scores are BIT-equal to scoring every image on its own, and sampled slots are within 2e-5 of the oracle's
+    batch-1 loop (generate_gp_training_data_imagenet.py:221-266)."""
+    eng = eng18 if which == "resnet18" else eng101
+    sd = synth.make_state_dict(which)
+    imgs = synth.make_images(4, seed=31, kind="blobs")
+    felz = np.load(os.path.join(golden_dir, "segments_blobs.npz"))["segments"][0].astype(np.int32)
+    segs = [synth.grid_segments(), felz, synth.grid_segments(block=32), synth.grid_segments()]
+    sizes = [eng.max_batch // 2 + 3, eng.max_batch // 2 + 5, 7, eng.max_batch + 2]          # straddles, a small one, more than one batch
+    onoffs = [synth.random_onoff(m, int(sg.max()) + 1, seed=40 + i) for i, (m, sg) in enumerate(zip(sizes, segs))]
+    labels = [3, 17, 999, 500]
+    inputs = [imgs[0], scorer.to_tensor_normalize(imgs[1]), imgs[2], imgs[3]]
+    packed = eng.score_images(inputs, segs, onoffs, labels)
+    for i in range(4):
+        _o, s1, p1 = eng.score_masks(inputs[i], segs[i], onoffs[i], labels[i])
+        assert np.array_equal(packed[i][0], s1) and np.array_equal(packed[i][1], p1), "image %d" % i
+    for i, rows in ((0, [0, sizes[0] - 1]), (1, [4]), (3, [eng.max_batch + 1])):
+        x = scorer.to_tensor_normalize(imgs[i])
+        ref_s, ref_p = scorer.score_masks_reference_loop(sd, which, x, segs[i], onoffs[i][rows], labels[i])
+        assert np.abs(packed[i][0][rows] - ref_s).max() <= SCORE_TOL_TIGHT and (packed[i][1][rows] == ref_p).all()
+    assert eng.score_images([], [], [], []) == []
+    with pytest.raises(ValueError):
+        eng.score_images(inputs[:1], segs[:1], [onoffs[1]], labels[:1])            # S of the label map and of the rows differ
+
+
+def test_api_fill_tables_on_the_engine(eng18):
+    """api.fill_tables (what validate_many / validate_summed_many run): unmasked row + every window of several images in packed
+    batches -- the tables are bit-equal to SaliencySession.table() one image at a time, the base predictions to predict()."""
+    from network_interpretation_imagenet_amd import api
+    imgs = synth.make_images(3, seed=77, kind="blobs")
+    xs = [scorer.to_tensor_normalize(im) for im in imgs]
+    segs = [synth.grid_segments(block=32), synth.grid_segments(block=16), synth.grid_segments(block=56)]
+    base = [eng18.predict(x)[0] for x in xs]
+    targets = [base[0], (base[1] + 1) % 1000, base[2]]
+    packed = [api.SaliencySession(eng18, x, t, segments=sg, check_base=False) for x, t, sg in zip(xs, targets, segs)]
+    assert api.fill_tables(eng18, packed) == [True, False, True]
+    for s, x, sg, b in zip(packed, xs, segs, base):
+        one = api.SaliencySession(eng18, x, b, segments=sg)
+        assert s.base_pred == b and np.array_equal(s.table()[1], one.table()[1])         # argmax does not depend on the label
+        assert s.label != b or np.array_equal(s.table()[0], one.table()[0])               # softmax[label] does
+
+
 TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_layers_cifar_resnet56.npz")
 
 

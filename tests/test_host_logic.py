@@ -231,6 +231,17 @@ class FakeEngine:
         """The test double's own K5 (the real engine runs mpx_heatmap_accumulate)."""
         return scorer.summed_superpixel_labels(seg_rank, onoff, np.asarray(pred) == label)
 
+    max_batch = 24          # smaller than one coarse image's table + the next one's: groups of two images get packed
+
+    def score_images(self, images, segments, onoffs, labels):
+        """The packed entry (the real engine shares forward batches between the images; the scores are per row either way)."""
+        self.packed = getattr(self, "packed", 0) + 1
+        out = []
+        for im, sg, oo, lb in zip(images, segments, onoffs, labels):
+            s, p = scorer.score_masks_batched(self.sd, self.arch, torch.as_tensor(im), sg, oo, lb, chunk=16)
+            out.append((s.astype(np.float32), p.astype(np.int32)))
+        return out
+
 
 @pytest.fixture()
 def coarse_setup(tmp_path):
@@ -356,6 +367,31 @@ def test_api_validate_summed_many_pipelines_segmentation(coarse_setup):
     assert api.validate_summed_many(bad, eng, None, [2], workers=1) == {2: None}
     assert api.validate_gp_superpixel(bad, eng, None, 2) is None           # "wrong prediction": falls off the end upstream
     assert api.validate_summed_many(loader, eng, None, []) == {}
+
+
+def test_fill_tables_and_validate_many(coarse_setup):
+    """api.fill_tables scores the unmasked row + every window of several sessions through ONE packed engine call and leaves the
+    tables SaliencySession.table() would compute one image at a time; validate_many = validate() per image, same draws."""
+    eng, loader, seg, label, mask_dir = coarse_setup
+    x = loader[1][0]
+    a = api.SaliencySession(eng, x, label, segments=seg, check_base=False)
+    b = api.SaliencySession(eng, x, (label + 1) % 1000, segments=seg, check_base=False)
+    single = api.SaliencySession(eng, x, label, segments=seg)
+    assert api.fill_tables(eng, [a, b]) == [True, False] and eng.packed == 1
+    assert a.base_pred == label and np.abs(a.table()[0] - single.table()[0]).max() < 1e-6 and (a.table()[1] == single.table()[1]).all()   # (torch-CPU batches of another size: not bit-equal; the engine's are -- GPU test)
+    assert len(a.table()[0]) == 17 and api.fill_tables(eng, [a]) == [True] and eng.packed == 1       # cached: no second pass
+    loader3 = loader + [loader[1]]
+    want = api.validate(loader3, eng, None, 2, rng=random.Random(11))
+    api.configure(eval_img_index=2, num_mask_samples=12, segmenter=lambda img: seg, mask_dir=None, seed=5)
+    r = random.Random(11)
+    many = api.validate_many(loader3, eng, None, [2, 3], rng=r, workers=2)
+    assert many[2] == want and isinstance(many[3], int) and 0 <= many[3] <= 12
+    api.configure(eval_img_index=2, num_mask_samples=12, segmenter=lambda img: seg, mask_dir=str(mask_dir), seed=5)
+    api.validate_many(loader3, eng, None, [3], rng=random.Random(1), workers=1)
+    files, labels = api.load_images_from_folder(str(mask_dir / "img_3"))
+    assert len(files) == 12 and set(labels) <= {"0", "1"}
+    bad = [loader[0], (loader[1][0], torch.tensor([(label + 1) % 1000]))]
+    assert api.validate_many(bad, eng, None, [2], workers=1) == {2: None}
 
 
 def test_session_cache_checks_identity_and_is_bounded():
