@@ -88,19 +88,23 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv
                          const float* beta, const float* mean, const float* var, float eps);
 int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has weights */
 
-/* Kernel variant of layer i (tuning / test hook; results are identical up to fp32 summation order):
- * 0 = 128x256 tile, 8 waves, 3-stage LDS ring (1 workgroup per CU); 1 = 64x256, 4 waves side by side;
- * 2 = 128x128, 4 waves, 2-deep rings, 64 KB (2 workgroups per CU); 3 = as 2 with a 3-deep X ring (80 KB);
- * 4 = 64x192 (64 KB, 2 workgroups per CU); 5 = 64x128 (48 KB, 3 workgroups per CU).  64-row tiles are meant for
- * cout <= 64 layers.  6 = the 3x3 patch kernel (stride-1 3x3 layers whose input patch fits the LDS): the input is staged once
- * per 32-channel chunk and the 9 taps read it at row offsets.  7 = the 128x128 tile cut into 8 waves of 32x64 (124 VGPRs: two
- * workgroups = 16 waves per CU).  8 = tile 2 as a persistent kernel with a register epilogue (cout >= 128).  9 = 256x256 tile,
- * two 64-KB stages (1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0).  10 = persistent pipelined 256x128 kernel, three
- * stages running on across tiles (as 9, cin >= 128).  11 = persistent kernel with a 96-pixel tile's whole K extent resident in LDS and
- * all cout tiles swept over it (as 9, cin = 128 or 256).  A tile a layer is not eligible for returns MPX_E_ARG.
- * tile < 0 = default: 64-row tiles (1 / 4) for cout <= 64; 6 where eligible with cout >= 128, 0 for the other wide 3x3 layers;
- * of the 1x1 stride-1 layers the expanding ones 10 (cin >= 128 on 28x28 / 14x14 maps) or 7, the reducing ones 9 (cout % 256 == 0)
- * or 2; 2 for everything else. */
+/* Kernel variant of layer i (tuning / test hook; results are identical up to fp32 summation order).  The ids are exactly the
+ * kernels some layer class runs by default:
+ *   0 = 128x256 tile, 8 waves, 3-stage LDS ring, 1 workgroup per CU (wide stride-2 3x3 layers);
+ *   1 = 64x256, 4 waves side by side (cout <= 64: the stem and the 64 -> 64 3x3 layers);
+ *   2 = 128x128, 4 waves, 2-deep rings, 64 KB, 2 workgroups per CU (strided 1x1 layers, fc, everything without a better fit);
+ *   4 = 64x192, 64 KB, 2 workgroups per CU (1x1 layers with cout = 64);
+ *   6 = the 3x3 patch kernel (stride-1 3x3 layers whose input patch fits the LDS: the input is staged once per 32-channel chunk
+ *       and the 9 taps read it at row offsets);
+ *   7 = the 128x128 tile cut into 8 waves of 32x64 (124 VGPRs: two workgroups = 16 waves per CU; expanding 1x1 layers with
+ *       K = 64 or on 7x7 maps, and the K-concatenated conv3 + downsample launches);
+ *   9 = 256x256 tile, two 64-KB stages (reducing 1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0);
+ *  10 = persistent pipelined 256x128 kernel, three stages running on across tiles (expanding 1x1 stride-1 layers with
+ *       cout % 256 == 0, cin >= 128, on 28x28 / 14x14 maps).
+ * A tile a layer is not eligible for, or any other id, returns MPX_E_ARG; tile < 0 = the layer's default.  (Ids 3, 5, 8 and 11 of
+ * earlier rounds -- kernels that were measured and never became a default -- exist only in probe builds,
+ * tools/probes/build_experimental.sh.)  A non-default tile on a layer of a block tail makes mpx_forward run that block layer by
+ * layer (mpx_bottleneck_tail). */
 int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
 int mpx_get_conv_tile(const mpx_engine* h, int i);
 

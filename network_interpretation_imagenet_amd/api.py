@@ -22,7 +22,7 @@ from . import masks
 from .engine import BasePredictionWrong, rank_segments, IMG
 
 __all__ = ["SaliencySession", "sample_loss", "validate_nueral_network", "superpixel_mask",
-           "validate", "validate_gp_superpixel", "validate_summed", "validate_summed_many", "validate_many", "fill_tables",
+           "validate", "validate_gp_superpixel", "validate_summed", "validate_summed_many", "validate_many", "fill_tables", "eval_superpixel",
            "score_masks", "default_segmenter",
            "jet_heatmap_u8",
            "img_show_u8", "load_images_from_folder", "prepare_training_data", "get_pixel_sorted_mask_label",
@@ -384,6 +384,49 @@ def validate_many(val_loader, model, criterion, eval_img_indices, num_mask_sampl
                 _write_png(os.path.join(d, "mask_{}_{}.png".format(i, int(ok))), s.mask_u8(f))
         return int(correct.sum())
     return _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, lookahead, emit)
+
+
+# the two small-network scripts' constants: (superpixels removed per mask, felzenszwalb min_size, image index, burn the unused randint)
+_SMALLNET_DEFAULTS = {"cifar": (5, 10, 5, False),      # generate_gp_training_data_cifar.py:308,284,281
+                      "mnist": (1, 5, 2, True)}        # generate_gp_training_data_mnist.py:206-215,181,177
+
+
+def eval_superpixel(test_loader, model, eval_img_index=None, num_removed=None, num_mask_samples=1000, min_size=None,
+                    rng=None, segments=None):
+    """-> correct_pred_count (int): eval_superpixel() of the reference's CIFAR / MNIST scripts
+    (generate_gp_training_data_cifar.py:236-342, generate_gp_training_data_mnist.py:153-269) for the image at
+    `eval_img_index` of the loader (1-based; CIFAR script: 5, MNIST script: 2): min-max the picture to u8, felzenszwalb(scale=100,
+    sigma=0.5, min_size = 10 / 5), then num_mask_samples (1000 upstream) masks, each switching OFF num_removed (5 / 1) superpixels
+    drawn with random.sample(range(uniq[0], uniq[-1]), k); a mask counts as correct when the masked prediction is still the target.
+    Unlike the ImageNet generators these scripts do NOT gate on the unmasked prediction (it is computed and unused, :289-290).
+    `model` is a MaskedForwardEngine("cifar_resnet56" / "mnist_net", ...) -- all masks of the image are one batched pass
+    (score_masks_removed: the scorers' double min-max convention on the device); the defaults follow the script the engine's
+    architecture belongs to.  With configure(mask_dir=...) writes mask_{i}_{0|1}.png = the {0,255} mask exactly as the scripts do
+    (:329-335).  `segments` overrides the segmentation (any integer label map)."""
+    fam = "mnist" if getattr(model, "arch", "").startswith("mnist") else "cifar"
+    d_removed, d_min, d_index, burn = _SMALLNET_DEFAULTS[fam]
+    k = d_removed if num_removed is None else int(num_removed)
+    idx = d_index if eval_img_index is None else int(eval_img_index)
+    item = _pick(test_loader, idx)
+    if item is None:
+        return 0
+    x = torch.as_tensor(item[0])
+    x = (x[0] if x.dim() == 4 else x).contiguous().to(torch.float32)
+    label = _as_int(item[1])
+    if segments is None:
+        from . import segment
+        segments = segment.felzenszwalb(img_show_u8(x.numpy()), scale=100, sigma=0.5, min_size=d_min if min_size is None else int(min_size))
+    segments = np.asarray(segments)
+    uniq = np.unique(segments)
+    rng = rng or (random.Random(_CONFIG["seed"]) if _CONFIG["seed"] is not None else random)
+    sets = masks.draw_removed_sets(uniq, k, num_mask_samples, rng, burn_window_draw=burn)
+    _r, _score, pred = model.score_masks_removed(x.numpy(), segments, masks.removed_onoff(uniq, sets), label)
+    correct = np.asarray(pred) == label
+    if _CONFIG["mask_dir"]:
+        os.makedirs(_CONFIG["mask_dir"], exist_ok=True)
+        for i, (vals, ok) in enumerate(zip(sets, correct)):
+            _write_png(os.path.join(_CONFIG["mask_dir"], "mask_{}_{}.png".format(i, int(ok))), masks.removed_mask_u8(segments, vals))
+    return int(correct.sum())
 
 
 def load_images_from_folder(folder):

@@ -3,11 +3,16 @@
 #include "../../include/mpx.h"
 #include "mpx_kernels.h"
 #include "mpx_conv3p.h"
-#include "mpx_convp.h"
 #include "mpx_conv256.h"
 #include "mpx_convx.h"
-#include "mpx_convs.h"
 #include "mpx_btail.h"
+#ifdef MPX_EXPERIMENTAL
+// Kernels that were measured in the network and did not become any layer class's default: tile ids 3 and 5 (other
+// shapes of the generic kernel), 8 (persistent kernel with a register epilogue) and 11 (pixel-stationary expanding 1x1 kernel).
+// They live under tools/probes/experimental/ and are compiled into probe builds only (tools/probes/build_experimental.sh).
+#include "../../tools/probes/experimental/mpx_convp.h"
+#include "../../tools/probes/experimental/mpx_convs.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -495,6 +500,7 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
     return 0;
 }
 
+#ifdef MPX_EXPERIMENTAL
 // Persistent kernel (mpx_convp.h, tile id 8 = the 128x128 4-wave tile): a fixed grid of
 // MINB-per-CU workgroups walks all tiles.
 template <class Cfg, bool DUAL = false>
@@ -514,6 +520,8 @@ int launch_convp_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
+
+#endif
 
 // 256x256 tile (mpx_conv256.h, tile id 9): 1x1 stride-1 layers whose cout is a multiple of 256 and whose K is a multiple of 64
 bool conv256_eligible(const ConvLayer& L) {
@@ -542,6 +550,7 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     return 0;
 }
 
+#ifdef MPX_EXPERIMENTAL
 // X-stationary expanding-1x1 kernel (mpx_convs.h, tile id 11): 1x1 stride-1 layers with cout % 256 == 0 and K = 128 or 256
 bool convs_eligible(const ConvLayer& L) { return conv256_eligible(L) && (L.cin_pad == 128 || L.cin_pad == 256); }
 
@@ -555,6 +564,8 @@ int launch_convs(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     MPX_HIP(h, hipGetLastError());
     return 0;
 }
+
+#endif
 
 int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = p.cout / Conv256::TC;
@@ -638,17 +649,20 @@ int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hi
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
     }
     switch (tile) {
-        case 11: return launch_convs(h, p, L.d.cout_pad, st);
         case 10: return launch_convx(h, p, L.d.cout_pad, st);
         case 9: return launch_conv256(h, p, L.d.cout_pad, st);
-        case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
-        case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
         case 7: return launch_conv_tile<ConvTile7>(h, p, L.d.cout_pad, st);
         case 4: return launch_conv_tile<ConvTile4>(h, p, L.d.cout_pad, st);
-        default: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
+#ifdef MPX_EXPERIMENTAL
+        case 11: return launch_convs(h, p, L.d.cout_pad, st);
+        case 8: return launch_convp_tile<ConvTile2>(h, p, L.d.cout_pad, st);
+        case 3: return launch_conv_tile<ConvTile3>(h, p, L.d.cout_pad, st);
+        case 5: return launch_conv_tile<ConvTile5>(h, p, L.d.cout_pad, st);
+#endif
+        default: return fail(h, MPX_E_INTERNAL, "conv: no kernel for tile id %d", tile);
     }
 }
 
@@ -740,7 +754,9 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
 #endif
     ProfScope ps(h, st, OP_CONV, i);
     if (L.tile == 2) return launch_conv_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
+#ifdef MPX_EXPERIMENTAL
     if (L.tile == 8) return launch_convp_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
+#endif
     return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);       // (tiles 7 and 10: the persistent kernel has no dual-operand form)
 }
 
@@ -1047,26 +1063,29 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile7::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv256_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
+#ifdef MPX_EXPERIMENTAL
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile3>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile3::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convp_f16x3_kernel<ConvTile2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile2::RING);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv256_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convs_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvS::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile5>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile5::LDS);
+        e = hipFuncSetAttribute((const void*)convs_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvS::LDS);
+#endif
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtResC64>, hipFuncAttributeMaxDynamicSharedMemorySize, BtResC64::LDS);
     if (e == hipSuccess)
@@ -1154,15 +1173,20 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    if (tile > 11) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d", tile);
+    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10
+    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10;
+#ifdef MPX_EXPERIMENTAL
+    known = known || tile == 3 || tile == 5 || tile == 8 || tile == 11;
     if (tile == 11 && !convs_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the pixel-stationary expanding-1x1 kernel (11) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin = 128 or 256 (%s is not one)", L.d.name);
+    if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
+#endif
+    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10)", tile);
     if (tile == 10 && !convx_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent expanding-1x1 kernel (10) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0, cin >= 128 (%s is not one)", L.d.name);
     if (tile == 9 && !conv256_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the 256x256 kernel (9) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0 (%s is not one)", L.d.name);
-    if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
-        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
     if (tile == 6 && !patch_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the patch kernel (6) needs a 3x3 stride-1 layer whose input patch fits the LDS (%s does not)", L.d.name);
     L.tile = tile;
@@ -1372,7 +1396,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10 || MAIN.tile == 11)) {
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10 || MAIN.tile == 11)) {      // (8, 11: experimental builds)
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

@@ -69,7 +69,7 @@ struct ConvParams {
     const half_t* x2_lo;
     int hin2, win2, pix_stride2, stride2;
     int k1;
-    int n_tiles;             // persistent kernels (mpx_convp.h): n_tiles_p * n_tiles_c, walked by a fixed grid
+    int n_tiles;             // persistent kernels (tools/probes/experimental/mpx_convp.h): n_tiles_p * n_tiles_c, walked by a fixed grid
 #ifdef MPX_DIAG
     unsigned long long* stamps;   // diagnostic build only (tools/probes/conv_timeline.py): 8 u64 per workgroup
 #endif
@@ -572,10 +572,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_f16x3_kernel(const ConvPa
 typedef ConvCfg<128, 256, 2, 4, 3, 3> ConvTile0;   // 8 waves, 144 KB LDS, 1 workgroup / CU
 typedef ConvCfg<64, 256, 1, 4, 2, 2> ConvTile1;    // cout <= 64: 4 waves side by side, each 64 cout x 64 pixels; 80 KB LDS, 2 workgroups / CU
 typedef ConvCfg<128, 128, 2, 2, 2, 2> ConvTile2;   // 4 waves, 2-deep rings, 64 KB LDS, 2 workgroups / CU
-typedef ConvCfg<128, 128, 2, 2, 2, 3> ConvTile3;   // as tile 2 with a 3-deep X ring (80 KB): measured 5-11 % slower (2 x 80 KB no longer co-reside)
 typedef ConvCfg<64, 192, 1, 4, 2, 2> ConvTile4;    // cout <= 64: 64 KB LDS, 2 workgroups / CU
-typedef ConvCfg<64, 128, 2, 2, 2, 2, 3> ConvTile5; // cout <= 64: 48 KB LDS, 3 workgroups / CU
-constexpr int CONV_NUM_TILES = 6;                  // ids 0..5; 6 = the 3x3 patch kernel (mpx_conv3p.h)
+#ifdef MPX_EXPERIMENTAL                            // probe builds only (no layer class's default): ids 3 and 5
+typedef ConvCfg<128, 128, 2, 2, 2, 3> ConvTile3;   // as tile 2 with a 3-deep X ring (80 KB): measured 5-11 % slower (2 x 80 KB no longer co-reside)
+typedef ConvCfg<64, 128, 2, 2, 2, 2, 3> ConvTile5; // cout <= 64: 48 KB LDS, 3 workgroups / CU: ties tile 2 at best, 3-20 % slower elsewhere
+#endif
+// id 6 = the 3x3 patch kernel (mpx_conv3p.h), 9 = mpx_conv256.h, 10 = mpx_convx.h
 // id 7: the 128x128 tile cut into 8 waves of 32 cout x 64 pixels: 124 VGPRs, so two workgroups = 16 waves per CU (4 per
 // SIMD).  Each wave issues half the LDS-DMA pieces and half the MFMAs of a tile-2 wave; with four waves per SIMD one
 // wave's DMA issue and barrier waits are covered by three others.

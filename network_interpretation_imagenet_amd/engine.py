@@ -407,6 +407,27 @@ class MaskedForwardEngine:
                    "mpx_heatmap_accumulate")
         return heat
 
+    def heatmap_device(self, image, seg_rank, onoff, label, buf):
+        """Score the M mask-vectors of one image and accumulate their heat map WITHOUT a host round trip:
+        buf (device f32[224*224 + 1]) gets heat[p] += sum_m [pred[m] == label] * onoff[m][seg[p]] in its first 224*224 elements
+        (K5, gp_superpixel_data_imagenet.py:322-323) and the number of correctly predicted masks added to its last element --
+        the layout shard.heatmap_sharded closes with ONE all_reduce.  -> (score f32[M], pred i32[M]) device tensors."""
+        if buf.dtype != torch.float32 or buf.device != self.device or buf.numel() != IMG * IMG + 1 or not buf.is_contiguous():
+            raise ValueError("buf must be a contiguous float32[%d] tensor on %s" % (IMG * IMG + 1, self.device))
+        onoff = np.ascontiguousarray(onoff, dtype=np.uint8)
+        m = int(onoff.shape[0])
+        score = torch.empty(m, dtype=torch.float32, device=self.device)
+        pred = torch.empty(m, dtype=torch.int32, device=self.device)
+        if m == 0:
+            return score, pred
+        seg_d = torch.from_numpy(np.ascontiguousarray(seg_rank, dtype=np.int32)).to(self.device)
+        onoff_d = torch.from_numpy(onoff).to(self.device)
+        labels = torch.full((m,), int(label), dtype=torch.int32, device=self.device)
+        self.score_packed([self._image_to_device(image)], seg_d, [onoff_d], labels, score, pred)
+        self.heatmap_accumulate(seg_d, onoff_d, pred, labels, buf[:IMG * IMG].view(IMG, IMG))
+        buf[IMG * IMG] += (pred == labels).sum()
+        return score, pred
+
     def heatmap(self, seg_rank, onoff, pred, label):
         """Host-array convenience over K5: -> f64[224,224] = sum_m [pred[m] == label] * onoff[m][seg[p]]
         (counts are integers < 2^24, so the f32 accumulation on the device is exact)."""

@@ -56,3 +56,44 @@ def expand_pixel_mask(seg_rank, onoff_row):
     """u8[H,W] in {0,1}: mask[y,x] = onoff[seg[y,x]] (host mirror of what K0 does on the device;
     used for the PNG wire format and heat-map reduction)."""
     return np.asarray(onoff_row, dtype=np.uint8)[seg_rank]
+
+
+# ---- the small networks' sampler (SURVEY.md 8 f4) ------------------------------------------------------------------------
+def draw_removed_sets(uniq, k, count, rng=None, burn_window_draw=False):
+    """The CIFAR / MNIST scorers' draw: `random.sample(range(np.unique(segments)[0], np.unique(segments)[-1]), k)` per mask
+    (generate_gp_training_data_cifar.py:308 with k = 5, generate_gp_training_data_mnist.py:215 with k = 1) -> `count` lists of k
+    superpixel LABEL VALUES to switch off.  The population is range(first, last): the LAST superpixel can never be drawn, and with
+    gaps in the labels a drawn value may name no superpixel (then `mask[segments == v] = 0` removes nothing).  Like
+    random.sample it raises ValueError when k exceeds the population.  burn_window_draw: the MNIST script first draws an unused
+    `firstIndex = randint(1, S - 1)` per mask (:210) -- consume it too, so that a seeded generator stays in step with upstream.
+    rng: random.Random (the reference uses the unseeded module-level generator)."""
+    rng = rng or random
+    uniq = np.asarray(uniq)
+    lo, hi = int(uniq[0]), int(uniq[-1])
+    out = []
+    for _ in range(int(count)):
+        if burn_window_draw:
+            rng.randint(1, len(uniq) - 1)
+        out.append(rng.sample(range(lo, hi), int(k)))
+    return out
+
+
+def removed_onoff(uniq, removed_sets):
+    """u8[M,S]: removed[m][s] = 1 when the s-th label of np.unique(segments) is in removed_sets[m] (the layout
+    MaskedForwardEngine.score_masks_removed / mpx_mask_apply_minmax take)."""
+    uniq = np.asarray(uniq)
+    out = np.zeros((len(removed_sets), len(uniq)), dtype=np.uint8)
+    for m, vals in enumerate(removed_sets):
+        if len(vals):
+            out[m] = np.isin(uniq, np.asarray(list(vals)))
+    return out
+
+
+def removed_mask_u8(segments, removed_set):
+    """u8[H,W] in {0,255}: `mask.fill(255); mask[segments == segVal] = 0` for the drawn values
+    (generate_gp_training_data_cifar.py:310-313) -- the picture the scorers write as mask_{i}_{label}.png."""
+    seg = np.asarray(segments)
+    mask = np.full(seg.shape, 255, dtype=np.uint8)
+    if len(removed_set):
+        mask[np.isin(seg, np.asarray(list(removed_set)))] = 0
+    return mask

@@ -101,11 +101,16 @@ def all_reduce_heatmap(heat, group=None):
     return heat
 
 
+HEAT_ELEMS = 224 * 224
+
+
 def heatmap_sharded(engine, image, segments, onoff, label, group=None):
     """Heat map of ONE image with its M mask-vectors split over the ranks (contiguous blocks of the mask axis):
-    each rank scores its block, accumulates sum_m [pred[m] == label] * onoff[m][seg[p]] on its device (K5,
-    engine.heatmap_accumulate) and one all-reduce yields the full f32[224,224] map on every rank -- equal to the
-    single-engine map exactly (integer counts).  `segments` must be a rank map (engine.rank_segments).
+    each rank scores its block and accumulates sum_m [pred[m] == label] * onoff[m][seg[p]] straight into a device buffer
+    f32[224*224 + 1] (K5 through engine.heatmap_device: no host round trip) whose LAST element carries the rank's number of
+    correctly predicted masks, and ONE all_reduce(SUM) of that buffer closes the image ("one all_reduce of
+    f32[224*224] per image"; the count rides along).  Equal to the single-engine map exactly: integer counts below 2^24, so the
+    f32 sum does not depend on the reduction order.  `segments` must be a rank map (engine.rank_segments).
     returns (heat f32[224,224] tensor on the engine's device, n_correct int over all ranks)."""
     import numpy as np
     m = int(onoff.shape[0])
@@ -115,15 +120,17 @@ def heatmap_sharded(engine, image, segments, onoff, label, group=None):
         rank, world = 0, 1
     lo, hi = block(m, rank, world)
     device = getattr(engine, "device", torch.device("cpu"))
-    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
-        device = torch.device("cpu")
-    heat = torch.zeros(224, 224, dtype=torch.float32, device=device)
-    count = torch.zeros(1, dtype=torch.float32, device=device)
+    on_gloo = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo"
+    buf = torch.zeros(HEAT_ELEMS + 1, dtype=torch.float32, device=device)
     if hi > lo:
-        _o, _score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
-        part = engine.heatmap(segments, onoff[lo:hi], pred, label)            # f64[224,224] on the host, exact
-        heat += torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32)).to(device)
-        count += float((np.asarray(pred) == label).sum())
-    all_reduce_heatmap(heat, group)
-    all_reduce_heatmap(count, group)
-    return heat, int(count.item())
+        if hasattr(engine, "heatmap_device"):
+            engine.heatmap_device(image, segments, onoff[lo:hi], label, buf)
+        else:                           # engine stand-ins of the CPU tests: host K5
+            _o, _score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+            part = engine.heatmap(segments, onoff[lo:hi], pred, label)            # f64[224,224], exact
+            buf[:HEAT_ELEMS] = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32).ravel())
+            buf[HEAT_ELEMS] = float((np.asarray(pred) == label).sum())
+    if on_gloo and buf.device.type != "cpu":
+        buf = buf.cpu()
+    all_reduce_heatmap(buf, group)
+    return buf[:HEAT_ELEMS].view(224, 224), int(buf[HEAT_ELEMS].item())

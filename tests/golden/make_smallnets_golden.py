@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 g.build_seg()
-from network_interpretation_imagenet_amd import segment  # noqa: E402
+from network_interpretation_imagenet_amd import masks, segment  # noqa: E402
 from oracle import smallnets_ref as ref  # noqa: E402
 
 torch.set_num_threads(8)
@@ -89,7 +89,7 @@ def case(arch, sd, pictures, min_size, n_removed, n_masks, seed):
             l64 = ref.forward(sd64, torch.from_numpy(x[None]).double(), arch).numpy()[0]
         label = int(l32.argmax())
         # random.sample(range(uniq[0], uniq[-1]), n): the last label can never be drawn (..._cifar.py:306, ..._mnist.py:209)
-        removed_lists = [sorted(rnd.sample(range(int(uniq[0]), int(uniq[-1])), min(n_removed, len(uniq) - 1))) for _ in range(n_masks)]
+        removed_lists = [sorted(r) for r in masks.draw_removed_sets(uniq, min(n_removed, len(uniq) - 1), n_masks, rnd)]       # the package's sampler
         removed_lists[0] = []                                   # nothing removed: only the double min-max rescale acts
         org = ref.org_img_minmax255(x)
         inputs = np.stack([ref.masked_input(org, ref.removed_mask_u8(seg, r)) for r in removed_lists])

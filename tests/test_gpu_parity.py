@@ -195,24 +195,21 @@ def test_conv_layers_resnet101(eng101, name):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 7])
 @pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv3", "layer2.0.conv2", "layer3.5.conv2", "layer4.2.conv3"])
 def test_conv_every_tile_variant(eng101, name, tile):
-    """Each kernel variant (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""
-    if tile >= 8 and name == "layer1.0.conv1":
-        assert eng101._lib.mpx_set_conv_tile(eng101._h, _layer_index(eng101, name), tile) == -1     # persistent tile: cout >= 128
-        return
+    """Each shape of the generic kernel (mpx_set_conv_tile) on 1x1 / 3x3 / strided / residual layers, odd batch (ragged tiles)."""
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=5, tile=tile)
 
 
-@pytest.mark.parametrize("tile", [8])
-@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 161), ("layer3.5.conv1", 201), ("layer2.1.conv3", 25), ("layer1.1.conv3", 25),
-                                        ("layer4.1.conv1", 401), ("layer3.0.conv2", 201)])
-def test_conv_persistent_kernel_many_tiles(eng101, name, tile, batch):
-    """The persistent kernel (csrc/mpx_convp.h) with MORE tiles than the 512 resident workgroups (600 .. 2000 tiles,
-    ragged last tile), so that workgroups walk several tiles: next-tile prologue under the epilogue, ring hand-over,
-    counted waits across tiles.  (mpx_conv_bn_act takes caller planes, so the batch is not bound by the engine's.)"""
-    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=tile)
+def test_conv_tile_ids_are_the_default_kernels(eng101):
+    """The documented tile ids are exactly what default_tile hands out; the ids of kernels that never became a default (3, 5, 8, 11:
+    probe builds only) and anything else are refused."""
+    i = _layer_index(eng101, "layer3.5.conv3")
+    for tile in (3, 5, 8, 11, 12):
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, tile) == -1
+    assert b"product ids" in eng101._lib.mpx_last_error(eng101._h)
+    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10}
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
@@ -246,22 +243,44 @@ def test_convx_persistent_expanding_kernel(eng101, name, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=10)
 
 
-@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 1), ("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv3", 161),
-                                        ("layer2.1.conv3", 3), ("layer2.1.conv3", 25), ("layer4.2.conv3", 9), ("layer3.5.conv1", 9)])
-def test_convs_pixel_stationary_expanding_kernel(eng101, name, batch):
-    """Tile id 11 (csrc/mpx_convs.h): persistent kernel that keeps a 96-pixel tile's whole K extent in LDS and sweeps all cout tiles
-    over it (two-stage weight ring that runs on across cout and pixel tiles, six-block fragment snake, register epilogue, counted
-    vmcnt waits).  Batches give a single ragged pixel tile (196 pixels = 2 full tiles + 4 pixels), one tile per workgroup, and
-    several per workgroup (161 x 196 pixels = 329 tiles on 256 CUs: pixel-tile boundaries, ragged last tile); K = 256 (8 steps per
-    cout tile) and K = 128 (4 steps, 28x28 maps).  K = 512 / 1024 layers are not eligible."""
-    i = _layer_index(eng101, name)
-    if eng101.layers[i].cin not in (128, 256):
-        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 11) == -1
-        return
-    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=11)
+def test_stress_sweep_distinct_shapes(eng101):
+    """A bounded slice of tools/stress_parity.py where the driver runs it: the 23 distinct conv shapes of ResNet-50 / 101 / 152
+    (they share them; stem and fc have tests of their own) x three ragged batches x EVERY kernel tile id the layer is eligible for, each against the fp64 conv + BN
+    (+ residual) (+ ReLU) on the same split inputs, <= 4e-6 relative."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    layers = sp.distinct_shape_layers(eng101)
+    assert len(layers) == 23                              # (cin, cout, k, stride, map, residual) without the stem and fc
+    n, worst = sp.sweep(eng101, synth.make_state_dict("resnet101"), layers, [1, 5, 9], seed=3)
+    print("stress sweep: %d (layer, batch, tile) cases, worst relative error %.2e" % (n, worst))
+    assert n >= 3 * 60 and worst <= 4e-6
 
 
-@pytest.mark.parametrize("tile", [-1, 2, 7, 8])
+def test_heatmap_device_and_one_buffer_layout(eng18):
+    """engine.heatmap_device (what shard.heatmap_sharded runs per rank): scores + K5 into a device buffer f32[224*224 + 1] whose last
+    element counts the correct masks -- equal to the host-array path exactly; a second image accumulates on top."""
+    from network_interpretation_imagenet_amd import shard
+    from network_interpretation_imagenet_amd.engine import rank_segments
+    img = synth.make_images(1, seed=12)[0]
+    seg, s = rank_segments(synth.grid_segments(block=28))
+    onoff = synth.random_onoff(37, s, seed=2)
+    label, _ = eng18.predict(img)
+    _o, score, pred = eng18.score_masks(img, seg, onoff, label)
+    want = eng18.heatmap(seg, onoff, pred, label)
+    buf = torch.zeros(224 * 224 + 1, dtype=torch.float32, device=eng18.device)
+    s_d, p_d = eng18.heatmap_device(img, seg, onoff, label, buf)
+    assert np.array_equal(s_d.cpu().numpy(), score) and np.array_equal(p_d.cpu().numpy(), pred)
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:-1].reshape(224, 224).astype(np.float64), want) and int(got[-1]) == int((pred == label).sum())
+    heat, n_ok = shard.heatmap_sharded(eng18, img, seg, onoff, label)              # single process: same buffer, no collective
+    assert heat.device == eng18.device and np.array_equal(heat.cpu().numpy().astype(np.float64), want) and n_ok == int(got[-1])
+    eng18.heatmap_device(img, seg, onoff[:5], label, buf)
+    assert int(buf[-1].item()) == int(got[-1]) + int((pred[:5] == label).sum())
+
+
+@pytest.mark.parametrize("tile", [-1, 2, 7])
 @pytest.mark.parametrize("stage", [1, 2, 3, 4])
 def test_conv_with_fused_downsample(eng101, stage, tile):
     """mpx_conv_dual_bn_act: layerN.0.conv3 + layerN.0.downsample K-concatenated in one launch (the default path of
@@ -457,7 +476,7 @@ def eng18_trained(mpx_lib, dev):
     e.close()
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 2, 5])
+@pytest.mark.parametrize("tile", [-1, 0, 2, 4])
 @pytest.mark.parametrize("name", ["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"])
 def test_conv_trained_cifar_weights(eng18_trained, name, tile):
     """Real trained conv + BN pairs (reference checkpoint cifar10+-resnet-56, layer3.4 / layer3.8; BN variances from
@@ -502,8 +521,8 @@ def test_set_conv_tile_errors(eng18):
     assert eng18._lib.mpx_set_conv_tile(eng18._h, 1, 17) == -1
     assert eng18._lib.mpx_get_conv_tile(eng18._h, 999) == -1
     default = eng18.conv_tile(1)
-    eng18.set_conv_tile(1, 3)
-    assert eng18.conv_tile(1) == 3
+    eng18.set_conv_tile(1, 4)
+    assert eng18.conv_tile(1) == 4
     eng18.set_conv_tile(1, -1)
     assert eng18.conv_tile(1) == default
 
@@ -978,6 +997,43 @@ def test_trained_small_network_end_to_end(mpx_lib, dev, golden_dir, arch):
         with pytest.raises(ValueError):
             eng.score_masks(np.zeros((224, 224, 3), dtype=np.uint8), np.zeros((224, 224), dtype=np.int32), np.ones((1, 1), dtype=np.uint8), 0)
     finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("arch", ["mnist_net", "cifar_resnet56"])
+def test_eval_superpixel_png_labels_follow_the_oracle_loop(mpx_lib, dev, golden_dir, tmp_path, arch):
+    """api.eval_superpixel = eval_superpixel() of generate_gp_training_data_cifar.py:236-342 / generate_gp_training_data_mnist.py:
+    153-269 on the engine: the package's sampler (masks.draw_removed_sets), all masks in batched passes, mask_{i}_{0|1}.png =
+    the {0,255} mask as the scripts write it.  The PNG labels and the returned count equal `pred == label` of the oracle's
+    one-mask-at-a-time loop on the same draws, the PNG pixels the oracle's mask picture."""
+    import random
+    from PIL import Image
+    from network_interpretation_imagenet_amd import api
+    from oracle import smallnets_ref
+    g, sd = _smallnet_case(arch, golden_dir)
+    eng = MaskedForwardEngine(arch, max_batch=16, device=0).load_state_dict(sd)
+    k, burn = (1, True) if arch == "mnist_net" else (5, False)
+    try:
+        x, seg, label = g["pic1/x"], g["pic1/segments"], int(g["pic1/label"])
+        loader = [(torch.zeros(1, *x.shape), torch.tensor([0])), (torch.from_numpy(x)[None], torch.tensor([label]))]
+        api.configure(mask_dir=str(tmp_path / "masks"))
+        n_ok = api.eval_superpixel(loader, eng, eval_img_index=2, num_mask_samples=40, rng=random.Random(5), segments=seg)
+        sets = masks.draw_removed_sets(np.unique(seg), k, 40, random.Random(5), burn_window_draw=burn)
+        _score, ref_pred = smallnets_ref.score_removed_loop(sd, arch, x, seg, sets, label)
+        files, labels = api.load_images_from_folder(str(tmp_path / "masks"))
+        assert len(files) == 40
+        by_i = {int(os.path.basename(f).split("_")[1]): (f, int(l)) for f, l in zip(files, labels)}
+        assert [by_i[i][1] for i in range(40)] == [int(p == label) for p in ref_pred] and n_ok == int((ref_pred == label).sum())
+        for i in (0, 7, 39):
+            assert np.array_equal(np.asarray(Image.open(by_i[i][0])), smallnets_ref.removed_mask_u8(seg, sets[i]))
+        # the script's own defaults: image index, superpixels per mask and min_size follow the engine's architecture; native segmentation
+        api.configure(mask_dir=None)
+        idx = 2 if arch == "mnist_net" else 5
+        loader5 = [loader[0]] * (idx - 1) + [loader[1]]
+        n2 = api.eval_superpixel(loader5, eng, num_mask_samples=30, rng=random.Random(6))
+        assert 0 <= n2 <= 30 and api.eval_superpixel(loader5[:idx - 1], eng, num_mask_samples=3) == 0
+    finally:
+        api.configure(mask_dir=None)
         eng.close()
 
 

@@ -444,3 +444,62 @@ def test_api_wrong_base_prediction(coarse_setup):
         api.sample_loss([1], bad, eng, None)
     assert api.validate(bad, eng, None, 2) == 0
     assert api.validate(loader, eng, None, 5) == 0                # index past the end of the loader
+
+
+# ------------------------------------------------------------------------------------------------
+# the small networks' sampler and mask pictures
+# ------------------------------------------------------------------------------------------------
+def test_draw_removed_sets_support_and_stream():
+    """masks.draw_removed_sets = random.sample(range(uniq[0], uniq[-1]), k) per mask (generate_gp_training_data_cifar.py:308,
+    generate_gp_training_data_mnist.py:215): the last superpixel is never drawn, the values of a set are distinct, a seeded
+    generator gives upstream's own stream (with the MNIST script's unused randint consumed when asked)."""
+    from network_interpretation_imagenet_amd import masks
+    uniq = np.arange(3, 15)                              # labels 3 .. 14
+    sets = masks.draw_removed_sets(uniq, 5, 400, random.Random(1))
+    flat = np.array(sets)
+    assert flat.shape == (400, 5) and flat.min() == 3 and flat.max() == 13          # 14, the last label, never
+    assert all(len(set(r)) == 5 for r in sets) and set(flat.ravel()) == set(range(3, 14))
+    r1, r2 = random.Random(7), random.Random(7)
+    assert masks.draw_removed_sets(uniq, 5, 10, r1) == [r2.sample(range(3, 14), 5) for _ in range(10)]
+    r1, r2 = random.Random(7), random.Random(7)
+    want = []
+    for _ in range(10):
+        r2.randint(1, len(uniq) - 1)                     # firstIndex = randint(1, S - 1), drawn and unused upstream
+        want.append(r2.sample(range(3, 14), 1))
+    assert masks.draw_removed_sets(uniq, 1, 10, r1, burn_window_draw=True) == want
+    with pytest.raises(ValueError):
+        masks.draw_removed_sets(np.arange(4), 5, 1, random.Random(0))               # population of 3 < k, as random.sample
+
+
+def test_removed_onoff_and_mask_picture_match_the_oracle_and_the_fixture(golden_dir):
+    from network_interpretation_imagenet_amd import masks
+    from oracle import smallnets_ref
+    for arch, k, seed in (("mnist_net", 1, 11), ("cifar_resnet56", 5, 12)):
+        g = np.load(os.path.join(golden_dir, "smallnet_%s.npz" % arch))
+        rnd = random.Random(seed)                        # the generator script's stream: one generator over both pictures
+        for i in range(int(g["n_pictures"])):
+            seg = g["pic%d/segments" % i]
+            uniq = np.unique(seg)
+            sets = [sorted(r) for r in masks.draw_removed_sets(uniq, min(k, len(uniq) - 1), 24, rnd)]
+            sets[0] = []
+            onoff = masks.removed_onoff(uniq, sets)
+            assert np.array_equal(onoff, g["pic%d/removed" % i])                    # the committed fixture was drawn by this sampler
+            assert np.array_equal(onoff, smallnets_ref.removed_onoff(seg, sets))
+            for r in sets[:4]:
+                m = masks.removed_mask_u8(seg, r)
+                assert m.dtype == np.uint8 and np.array_equal(m, smallnets_ref.removed_mask_u8(seg, r))
+    gaps = np.array([[2, 2, 7], [7, 9, 9]])              # labels with gaps: a drawn value may name no superpixel
+    assert masks.removed_onoff(np.unique(gaps), [[3, 7]]).tolist() == [[0, 1, 0]]
+    assert masks.removed_mask_u8(gaps, [3, 7]).tolist() == [[255, 255, 0], [0, 255, 255]]
+
+
+def test_jet_lut_bytes_are_pinned():
+    """api.jet_heatmap_u8's LUT (parity unpinned against OpenCV's table, which is absent here: INTEGRATION.md): its own bytes are
+    pinned at the end points and the four breakpoints of the piecewise-linear jet, so that an edit cannot drift silently."""
+    ramp = np.arange(256, dtype=np.float64).reshape(16, 16)
+    bgr = api.jet_heatmap_u8(ramp).reshape(256, 3)
+    want = {0: (128, 0, 0), 31: (252, 0, 0), 32: (255, 0, 0), 95: (255, 252, 0), 96: (254, 255, 1), 159: (1, 255, 254), 160: (0, 252, 255),
+            223: (0, 0, 255), 224: (0, 0, 252), 255: (0, 0, 128)}
+    got = {i: tuple(int(v) for v in bgr[i]) for i in want}
+    assert got == want, got
+    assert (np.diff(bgr[:, 2].astype(int))[:223] >= 0).all() and (np.diff(bgr[:, 0].astype(int))[32:] <= 0).all()      # R rises, B falls

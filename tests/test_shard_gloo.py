@@ -113,8 +113,14 @@ def _heat_worker(rank, world, port, m, out_dir):
     try:
         rng = np.random.default_rng(11)
         onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
-        heat, n_ok = shard.heatmap_sharded(_TableEngine(), None, _seg23(), onoff, 3)
-        np.savez(os.path.join(out_dir, "h%d.npz" % rank), heat=heat.numpy(), n_ok=n_ok)
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), real(t, *a, **k))[1]
+        try:
+            heat, n_ok = shard.heatmap_sharded(_TableEngine(), None, _seg23(), onoff, 3)
+        finally:
+            dist.all_reduce = real
+        np.savez(os.path.join(out_dir, "h%d.npz" % rank), heat=heat.numpy(), n_ok=n_ok, collectives=np.array(calls))
     finally:
         dist.destroy_process_group()
 
@@ -135,3 +141,4 @@ def test_heat_map_all_reduce_two_ranks(tmp_path, m):
         got = np.load(tmp_path / ("h%d.npz" % r))
         assert got["heat"].dtype == np.float32 and (got["heat"].astype(np.float64) == want).all()
         assert int(got["n_ok"]) == n_single
+        assert got["collectives"].tolist() == [224 * 224 + 1]          # ONE all_reduce per image: the map with the count as its last element

@@ -11,7 +11,7 @@ import __graft_entry__ as g  # noqa: E402
 
 g.build()
 from network_interpretation_imagenet_amd import synth  # noqa: E402
-from network_interpretation_imagenet_amd.engine import MaskedForwardEngine  # noqa: E402
+from network_interpretation_imagenet_amd.engine import MaskedForwardEngine, MpxError  # noqa: E402
 
 arch = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -30,10 +30,11 @@ if os.environ.get("MPX_TILE_PATCH"):      # tool-only override: patch kernel (ti
     for i, d in enumerate(eng.layers):
         try:
             eng.set_conv_tile(i, 6)
-        except Exception:
+        except MpxError:
             pass
-if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with classes k1exp k1red k1s2 k3s2 c64k1 c64k3 stem
+if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with classes k1exp k1red k1s2 k3s1 k3s2 c64k1 c64k3 stem
     rules = dict(r.split(":") for r in os.environ["MPX_TILE_RULES"].split(","))
+    took, kept = {}, {}
     for i, d in enumerate(eng.layers):
         if d.cin == 3:
             cls = "stem"
@@ -48,8 +49,11 @@ if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with clas
         if cls in rules and d.name != b"fc":
             try:
                 eng.set_conv_tile(i, int(rules[cls]))
-            except Exception:           # the layer is not eligible for that kernel: keep its default
-                pass
+                took[cls] = took.get(cls, 0) + 1
+            except MpxError:            # the layer is not eligible for that kernel: it keeps its default -- and says so
+                kept[cls] = kept.get(cls, 0) + 1
+    for cls in rules:
+        print("rule %s:%s -> %d layers took the tile, %d kept their default (not eligible)" % (cls, rules[cls], took.get(cls, 0), kept.get(cls, 0)))
 if os.environ.get("MPX_TILE_1X1"):      # tool-only override: one tile variant on every 1x1 conv with cout >= 128
     for i, d in enumerate(eng.layers):
         if d.ksize == 1 and d.cout >= 128:

@@ -17,15 +17,9 @@ DIAG = os.path.join(HERE, "libmpx_diag.so")
 
 
 def build_diag():
-    import __graft_entry__ as g
-    flags = g.HIPCC_FLAGS + ["-DMPX_DIAG"]
-    want = g._source_hash(g.lib_sources(), flags)
-    stamp = DIAG + ".sha256"
-    if os.path.exists(DIAG) and os.path.exists(stamp) and open(stamp).read().strip() == want:
-        return
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-o", DIAG, os.path.join(g.CSRC, "mpx_api.hip")], cwd=g.CSRC)
-    with open(stamp, "w") as fh:
-        fh.write(want + "\n")
+    sys.path.insert(0, HERE)
+    import conv_timeline
+    conv_timeline.build_diag()
 
 
 if __name__ == "__main__":

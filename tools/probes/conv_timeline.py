@@ -23,13 +23,22 @@ sys.path.insert(0, ROOT)
 DIAG = os.path.join(HERE, "libmpx_diag.so")
 
 
-def build_diag():
+def build_diag(extra_flags=()):
+    """-DMPX_DIAG build of the library next to this file.  Rebuilt when the sha256 of its sources + flags differs from the stamp
+    written at build time (mtimes mean nothing once the tree has been copied to the GPU box, __graft_entry__._stale)."""
     import __graft_entry__ as g
+    flags = g.HIPCC_FLAGS + ["-DMPX_DIAG"] + list(extra_flags)
     srcs = g.lib_sources()
-    if os.path.exists(DIAG) and all(os.path.getmtime(DIAG) >= os.path.getmtime(s) for s in srcs):
+    if extra_flags:
+        import glob
+        srcs = srcs + sorted(glob.glob(os.path.join(HERE, "experimental", "*.h")))
+    want = g._source_hash(srcs, flags)
+    stamp = DIAG + ".sha256"
+    if os.path.exists(DIAG) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + g.HIPCC_FLAGS + ["-DMPX_DIAG", "-o", DIAG,
-                          os.path.join(g.CSRC, "mpx_api.hip")], cwd=g.CSRC)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-o", DIAG, os.path.join(g.CSRC, "mpx_api.hip")], cwd=g.CSRC)
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
 
 
 if __name__ == "__main__":

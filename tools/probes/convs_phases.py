@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the pixel-stationary kernel (tile 11, csrc/mpx_convs.h) spend a workgroup's life?  -DMPX_DIAG build (never the product
+"""Where does the pixel-stationary kernel (tile 11, tools/probes/experimental/mpx_convs.h) spend a workgroup's life?  -DMPX_DIAG build (never the product
 library): per workgroup the cycles spent in the per-step rendezvous (vmcnt wait + barrier), waiting for the epilogue loads, in the
 epilogue itself, and waiting for the next pixel tile.   usage: python tools/probes/convs_phases.py [layer] [batch]"""
 import ctypes as C
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 import conv_timeline as ct  # noqa: E402  (build_diag)
 
-ct.build_diag()
+ct.build_diag(["-DMPX_EXPERIMENTAL"])      # tile 11 lives in tools/probes/experimental/ (never a default: DESIGN.md 5)
 from network_interpretation_imagenet_amd import _lib, synth  # noqa: E402
 _lib.LIB_PATH = ct.DIAG
 from network_interpretation_imagenet_amd.engine import MaskedForwardEngine  # noqa: E402

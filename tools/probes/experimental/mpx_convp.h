@@ -14,7 +14,7 @@
 // with out-of-range offsets for masked lanes (never skipped), so every wave issues the same number of VMEM
 // instructions per tile and all waits stay immediates.
 #pragma once
-#include "mpx_conv.h"
+#include "../../../network_interpretation_imagenet_amd/csrc/mpx_conv.h"
 
 namespace mpx {
 

@@ -24,7 +24,7 @@
 // vmcnt bookkeeping (loads, LDS-DMAs and stores retire in issue order; every wave issues the same instruction counts -- masked
 // lanes carry an out-of-range offset): see the WAIT_* constants at the waits.
 #pragma once
-#include "mpx_conv.h"
+#include "../../../network_interpretation_imagenet_amd/csrc/mpx_conv.h"
 
 namespace mpx {
 
