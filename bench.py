@@ -47,14 +47,15 @@ def parse():
 
 def pmc_traffic(arch, batch):
     """HBM bytes of the conv kernels per forward batch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    cannot be read from inside the process); None unless a profile of this arch and forward batch exists."""
+    cannot be read from inside the process) -> (bytes per forward batch, file name); (None, None) unless a profile of this arch
+    and forward batch exists."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")), reverse=True):
         with open(path) as fh:
             j = json.load(fh)
         if j.get("forward_batch") == batch and arch == j.get("arch", "resnet101"):
-            return j["write_bytes_per_batch"] + j["fetch_corrected_bytes_per_batch_guide_x2"]       # per forward batch
-    return None
+            return j["write_bytes_per_batch"] + j["fetch_corrected_bytes_per_batch_guide_x2"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def _cpu_model():
@@ -212,7 +213,7 @@ def main():
         conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
         flops_per_batch = eng.flops_per_forward * batch
         roofline = None
-        traffic_per_batch = pmc_traffic(args.arch, batch)
+        traffic_per_batch, traffic_source = pmc_traffic(args.arch, batch)
         if conv_n:
             # dominant kernel = conv_f16x3_kernel (all conv/fc launches).  achieved = algorithmic FLOPs
             # of the launches / their summed HIP-event durations; MFMA-issued FLOPs are 3x algorithmic.
@@ -222,7 +223,9 @@ def main():
                         # HBM bytes per conv launch = PMC bytes of the conv kernels per forward batch / conv launches per batch (a
                         # launch = one layer; 26 of them split their last round off into a second, small kernel dispatch)
                         "traffic": (traffic_per_batch / (conv_n / batches_profiled)) if traffic_per_batch else None,
-                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel (all conv launches)", "launches": conv_n,
+                        # NOT measured in this run: PMC counters need rocprofv3; the file holds the per-batch bytes of the same forward
+                        "traffic_source": traffic_source, "traffic_bytes_per_forward_batch": traffic_per_batch,
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)

@@ -26,17 +26,19 @@ fetch_dir, write_dir, arch, batch, nb = sys.argv[1], sys.argv[2], sys.argv[3], i
 f, nf = total(fetch_dir, "FETCH_SIZE")
 w, nw = total(write_dir, "WRITE_SIZE")
 assert nf and nf == nw and nf % nb == 0, (nf, nw, nb)
-launches = nf // nb
 fetch = f * 1024 / nb
 write = w * 1024 / nb
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) --kernel-trace -- python3 tools/layer_profile.py "
-              "%s %d; conv launches only (conv_f16x3_kernel, conv3x3p_f16x3_kernel), per forward batch of %d masked images" % (arch, batch, batch),
+              "%s %d; every kernel whose name contains _f16x3_kernel = all conv launches (conv_f16x3_kernel, conv3x3p_f16x3_kernel, "
+              "conv256_f16x3_kernel, convx_f16x3_kernel, btail_f16x3_kernel), per forward batch of %d masked images" % (arch, batch, batch),
     "arch": arch,
     "forward_batch": batch,
-    "launches_per_batch": launches,
+    # kernel dispatches the counters were summed over: a layer whose last round of tiles is split off runs as two dispatches, so this
+    # is larger than the engine's launch count; bench.py divides the bytes by ITS OWN conv-launch count (one denominator, stated there)
+    "dispatches_per_batch": nf // nb,
     "write_bytes_per_batch": write,
     "fetch_raw_bytes_per_batch": fetch,
     "fetch_corrected_bytes_per_batch_guide_x2": 2 * fetch,
-    "traffic_bytes_per_launch": (2 * fetch + write) / launches,
+    "total_bytes_per_batch": 2 * fetch + write,
 }, indent=1))
