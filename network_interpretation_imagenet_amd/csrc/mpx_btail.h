@@ -100,6 +100,17 @@ constexpr int BT_OFF_VEC = 0;                           // scale / shift vectors
 constexpr int BT_OFF_PATCH = 4096;
 constexpr int BT_OFF_RING = BT_OFF_PATCH + 4 * BT_BLK + 256;  // + slack: the dead lanes of the last patch row read 2 rows further
 constexpr int BT_MID = 64, BT_OUT = 256;
+#ifndef BT_AUX_LOAD
+#define BT_AUX_LOAD 2       // cache policy bits of the identity loads / output stores (2 = nt); probe builds override them
+#endif
+#ifndef BT_AUX_STORE
+#define BT_AUX_STORE 2
+#endif
+// timing-only ablations (probe builds, wrong results): BT_ABL bit 0 = patch DMAs, 1 = identity / block-input loads, 2 = stores,
+// 3 = weight DMAs carry an out-of-range offset: the instruction is still issued, the memory access is not made
+#ifndef BT_ABL
+#define BT_ABL 0
+#endif
 
 template <bool DUAL_, int C1_>
 struct BtCfg {
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     const __amdgpu_buffer_rsrc_t w3l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3_lo, 0, BT_OUT * S3 * 64, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1_hi, 0, (C1 ? C1 : 16) * BT_OUT * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1_lo, 0, (C1 ? C1 : 16) * BT_OUT * 2, 0x00020000);
-    const int w_lane = lane * 16;
+    const int w_lane = (lane * 16) | ((BT_ABL & 8) ? (int)OOB : 0);
     // stage JS of the tile program into ring slot `slot`: this wave moves piece `wave` (16 rows) of each plane
     auto issue_stage = [&](auto js_tag, int slot) {
         constexpr int JS = decltype(js_tag)::value;
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
             const int idx = wave * 10 + i;
             const int py = idx >> 2, s = (idx >> 1) & 1, plane = idx & 1;
             const int iy = y0 - 1 + py;
-            const int voff = (col + iy * p.W * BT_MID * 2) | col_oob | ((iy | (p.H - 1 - iy)) & (int)OOB);
+            const int voff = (col + iy * p.W * BT_MID * 2) | col_oob | ((iy | (p.H - 1 - iy)) & (int)OOB) | (((BT_ABL & 1) && it > 0) ? (int)OOB : 0);
             char* const d = patch + (s * 2 + plane) * BT_BLK + py * 1024;
             if (plane == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(th, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(tl, MPX_LDS_PTR(d), 16, voff, s * 64, 0, 0);
@@ -338,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         auto issue_identity = [&](int c) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB);
-                idh[u] = __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, c * 128, 2);
-                idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, c * 128, 2);
+                const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 2) ? (int)OOB : 0);
+                idh[u] = __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, c * 128, BT_AUX_LOAD);
+                idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, c * 128, BT_AUX_LOAD);
             }
         };
         auto read_a1 = [&](int slot, FragA& f, int i) {        // fragment read i = 0..7 of a stage: hi rows 0..3, lo rows 0..3
@@ -530,9 +541,9 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                     }
                     h8 oh, ol;
                     bt_relu_split8(v, one, oh, ol);
-                    const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), yh, voff, c * 128, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff, c * 128, 2);
+                    const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 4) ? (int)OOB : 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), yh, voff, c * 128, BT_AUX_STORE);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff, c * 128, BT_AUX_STORE);
                     // operand layout for conv1': [fragment b][K step uq>>2][plane][16 slots][64 B], chunk uq&3 swizzled by the slot
                     char* const d = stg + (b * 4 + (uq >> 2) * 2) * 1024 + (slot & 15) * 64 + (((uq & 3) ^ (((slot >> 3) & 1) << 1)) << 4);
                     *(h8*)d = oh;
@@ -589,9 +600,9 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                 const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                 bt_relu_split8(v, one, zoh[u], zol[u]);
                 if (hb + 1 < H1) {
-                    const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, hb * 128, 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, hb * 128, 2);
+                    const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 4) ? (int)OOB : 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, hb * 128, BT_AUX_STORE);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, hb * 128, BT_AUX_STORE);
                 }
             }
         }
@@ -607,9 +618,9 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         BT_SUB(4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, (H1 - 1) * 128, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, (H1 - 1) * 128, 2);
+            const int voff = (u_pix[u] * (C1 * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 4) ? (int)OOB : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zoh[u]), zh, voff, (H1 - 1) * 128, BT_AUX_STORE);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, zol[u]), zl, voff, (H1 - 1) * 128, BT_AUX_STORE);
         }
         __builtin_amdgcn_sched_barrier(0);
         BT_SUB(3);

@@ -17,9 +17,10 @@ DIAG = os.path.join(HERE, "libmpx_diag.so")
 
 
 def build_diag():
+    """MPX_DIAG_FLAGS="-DBT_AUX_STORE=0 ..." adds compile flags (probe variants of the kernel)"""
     sys.path.insert(0, HERE)
     import conv_timeline
-    conv_timeline.build_diag()
+    conv_timeline.build_diag(os.environ.get("MPX_DIAG_FLAGS", "").split())
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ def build_diag(extra_flags=()):
     import __graft_entry__ as g
     flags = g.HIPCC_FLAGS + ["-DMPX_DIAG"] + list(extra_flags)
     srcs = g.lib_sources()
-    if extra_flags:
+    if "-DMPX_EXPERIMENTAL" in extra_flags:
         import glob
         srcs = srcs + sorted(glob.glob(os.path.join(HERE, "experimental", "*.h")))
     want = g._source_hash(srcs, flags)
