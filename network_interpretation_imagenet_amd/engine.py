@@ -290,11 +290,15 @@ class MaskedForwardEngine:
         if not 0 <= int(label) < NUM_CLASSES:
             raise ValueError("label %r outside [0,1000)" % (label,))
         m = onoff.shape[0]
+        if not return_logits:
+            # one upload, forwards of max_batch slots back to back, ONE download at the end (no per-chunk synchronisation)
+            score, pred = self.score_images([image], [seg_rank], [onoff], [label])[0]
+            return onoff, score, pred
         score = np.empty(m, dtype=np.float32)
         pred = np.empty(m, dtype=np.int32)
-        logits = np.empty((m, NUM_CLASSES), dtype=np.float32) if return_logits else None
+        logits = np.empty((m, NUM_CLASSES), dtype=np.float32)
         if m == 0:
-            return (onoff, score, pred, logits) if return_logits else (onoff, score, pred)
+            return onoff, score, pred, logits
         img_d = self._image_to_device(image)
         seg_d = torch.from_numpy(seg_rank).to(self.device)
         onoff_d = torch.from_numpy(onoff).to(self.device)
