@@ -11,7 +11,7 @@
 //     so the first stages of the next tile are already in LDS when the current tile ends -- no prologue, no dispatch gap;
 //   * K step = the quadrant snake of mpx_conv256.h (fragment halves A0/A1, B0/B1 = 64 VGPRs, one barrier per step);
 //   * the epilogue works from the accumulator registers (v_permlane16_swap + DPP row_ror:8 regrouping into full 128-B lines,
-//     mpx_convp.h) and needs no LDS and no barrier; its residual lines are requested two K steps before the tile ends, into
+//     tools/probes/experimental/mpx_convp.h) and needs no LDS and no barrier; its residual lines are requested two K steps before the tile ends, into
 //     registers that only the epilogue uses, and its stores retire under the next tile's K loop.
 // vmcnt bookkeeping (loads, LDS-DMAs and stores retire in issue order; every wave issues the same instructions -- masked lanes
 // carry an out-of-range offset): at the mid-step rendezvous of step s the stage s+1 must have landed; the instructions issued
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         }
     };
 
-    // ---- epilogue state: lane geometry of the regrouped 16-B chunks (mpx_convp.h) -------------------------------------------
+    // ---- epilogue state: lane geometry of the regrouped 16-B chunks (as tools/probes/experimental/mpx_convp.h) -------------------------------------------
     const int erow = lane >> 4;
     const bool lo8 = (lane & 8) == 0;
     int offA[4];
