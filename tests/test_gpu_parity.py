@@ -1060,6 +1060,17 @@ def test_small_network_ops(mpx_lib, dev, golden_dir):
         assert np.isnan(inputs).all()
         big = MaskedForwardEngine("resnet18", max_batch=1, device=0)
         assert big._lib.mpx_mask_apply_minmax(big._h, None, None, None, 1, 1, 0, None, None) == -2      # ImageNet engines refuse it
+        assert big.input_plane_shape(1) == (1, 230, 230, 4)
         big.close()
+        # the zero-copy staging view follows the engine's geometry: [n][32][32][32] here, not the ImageNet [n][230][230][4] (which
+        # would run far past the small arena); the staged values are the masked inputs in the first 3 of 32 channels
+        assert eng.input_plane_shape(3) == (3, 32, 32, 32)
+        _r, _s, _pr, inputs = eng.score_masks_removed(g[p + "x"], seg, g[p + "removed"][:3], int(g[p + "label"]), return_inputs=True)
+        hi, lo = eng.input_planes(3)
+        assert tuple(hi.shape) == (3, 32, 32, 32) and hi.numel() == 3 * 32 * 32 * 32
+        staged = merge(hi, lo).cpu().numpy()
+        assert np.abs(staged[..., :3].transpose(0, 3, 1, 2) - inputs).max() <= 2.0 ** -21 * np.abs(inputs).max() and (staged[..., 3:] == 0).all()
+        with pytest.raises(ValueError):
+            eng.input_planes(5)                       # more slots than max_batch = 4
     finally:
         eng.close()
