@@ -3,7 +3,7 @@
 //     t2  = relu(bn2(conv2_3x3(t1)))                              64 -> 64, stride 1, pad 1      (never leaves the registers)
 //     out = relu(bn3(conv3_1x1(t2)) + identity)                   64 -> 256                      (written: the next block's identity)
 //           DUAL (first block of layer1): identity = bn_d(conv_d_1x1(x)) K-concatenated as in mpx_conv.h's DUAL kernel
-//     t1' = relu(bn1'(conv1'_1x1(out)))                           256 -> C1 (64, or 128 for layer2.0.conv1; 0 = none)
+//     t1' = relu(bn1'(conv1'_1x1(out)))                           256 -> C1 (64, or 128 for layer2.0.conv1)
 //                                                                 the NEXT block's first conv, from the tile that is still on chip
 //
 // Why: layer1 of the bottleneck ResNets is HBM-bound (56x56 maps; 24 % of the network's bytes for 3.5 % of its FLOPs).  Layer by
@@ -12,11 +12,11 @@
 // read ONCE per block (as the identity) instead of twice.  Everything behind conv2 is pointwise, so only the 64-channel t1 needs a
 // halo; nothing is recomputed.
 //
-// Workgroup = 4 waves, 80 KB LDS, two workgroups per CU (one's HBM-bound chunk epilogues overlap the other's MFMA-bound conv2),
+// Workgroup = 4 waves, 78 KB LDS, two workgroups per CU (one's memory- and VALU-heavy chunk epilogues overlap the other's MFMAs),
 // persistent over tiles.  Tile = 8 rows x 14 columns of one image (56 = 7 x 8 = 4 x 14); a 16-lane pixel fragment is one tile row
 // (lanes 14, 15 are dead: 12.5 % of the MFMA columns, nothing else).  Waves split the PIXELS (wave w = tile rows 2w, 2w+1 = two
 // fragments) and own all channels of them, so a wave's conv2 accumulators (D layout: lane = pixel, registers = channels) ARE the
-// B operand of its conv3 MFMAs under a permutation of K that is baked into the packed conv3 weights (mpx_api.hip, pack_w3_perm):
+// B operand of its conv3 MFMAs under a permutation of K that is baked into a copy of the packed conv3 weights (mpx_api.hip, upload_tail_planes):
 // K position 8g + j of a 32-wide step holds channel (j>>2)*16 + 4g + (j&3).
 //
 // LDS: [scale / shift vectors][t1 patch: 10 x 16 pixels x 64 channels x (hi, lo) = 40 KB; after conv2 the same bytes are four
@@ -28,10 +28,14 @@
 // area in operand layout -> B fragments of conv1' (natural K order).  No block barrier in the epilogues: a wave only touches its own
 // pixels.
 //
+// A step = one stage = 24 MFMAs per wave behind ONE counted vmcnt + barrier; the weight fragments of step J+1 are read between the
+// MFMAs of step J (register double buffer), stage J+4 is issued behind MFMA 1 into the slot of stage J.
 // vmcnt bookkeeping: LDS-DMAs, loads and stores retire in issue order.  Per step a wave issues one stage (2 pieces), then possibly
-// 8 identity loads (for the next chunk) and, at the end of a chunk's last conv3 step, 8 stores; BtSched computes the immediate of
-// every counted wait from that program.  The per-lane scale / shift vectors come from LDS so that no other vector-memory
-// instruction exists.  At a tile boundary the wave drains (the patch must land; the partner workgroup covers).
+// 8 identity loads (for the next chunk) and, behind a chunk's last conv3 step, 8 stores; BtCfg computes the immediate of every
+// counted wait from that program.  The per-lane scale / shift vectors come from LDS so that no other vector-memory instruction
+// exists.  At a tile boundary every wave waits for the next patch (requested behind the tile's last barrier, in front of its last 8
+// stores, which may stay in flight); the partner workgroup covers.  DESIGN.md 5b has the measurements (phases, ablations, what was
+// tried and dropped).
 #pragma once
 #include "mpx_conv.h"
 #include <type_traits>
