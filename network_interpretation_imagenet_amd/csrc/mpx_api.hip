@@ -799,10 +799,22 @@ int launch_stem_pool(mpx_engine* h, half_t* y_hi, half_t* y_lo, int B, hipStream
 // K permutation of a block tail's conv3 operand (mpx_btail.h): K position 8g + j of a 32-wide step holds channel (j>>2)*16 + 4g + (j&3),
 // because that is where the conv2 accumulators of a lane group g sit (D layout of v_mfma_f32_16x16x32_f16: registers 4g .. 4g+3 of
 // two stacked 16-row fragments).
-inline int bt_perm_channel(int kpos) {
+constexpr int bt_perm_channel(int kpos) {
     const int s = kpos >> 5, q = kpos & 31, g = q >> 3, j = q & 7;
     return 32 * s + (j >> 2) * 16 + 4 * g + (j & 3);
 }
+constexpr bool bt_perm_is_bijection() {        // every channel of [0,64) exactly once, each 32-wide K step onto its own 32 channels
+    bool seen[BT_MID] = {};
+    for (int k = 0; k < BT_MID; ++k) {
+        const int c = bt_perm_channel(k);
+        if (c < 0 || c >= BT_MID || seen[c] || (c >> 5) != (k >> 5)) return false;
+        seen[c] = true;
+    }
+    return true;
+}
+static_assert(bt_perm_is_bijection(), "K permutation of the block tail's conv3 operand");
+static_assert(bt_perm_channel(0) == 0 && bt_perm_channel(3) == 3 && bt_perm_channel(4) == 16 && bt_perm_channel(8) == 4 && bt_perm_channel(36) == 48,
+              "K position 8g + j <-> channel (j>>2)*16 + 4g + (j&3): registers 4g..4g+3 of two stacked 16-row accumulator fragments");
 
 // Upload the K-permuted copy of packed planes `hi`/`lo` ([rows >= 256][K], piece-major, host) into the tail's own planes:
 // columns [0,64) permuted, columns [64,K) (the downsample branch of a DUAL tail) as they are.

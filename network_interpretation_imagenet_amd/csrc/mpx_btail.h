@@ -651,4 +651,14 @@ typedef BtCfg<false, 64> BtResC64;      // layer1.1 / layer1.2 tails: identity =
 typedef BtCfg<false, 128> BtResC128;    // layer1's last block: next conv1 = layer2.0.conv1, 256 -> 128
 typedef BtCfg<true, 64> BtDualC64;      // layer1.0: downsample branch K-concatenated, next conv1 256 -> 64
 
+// The wait immediates, checked against the program written out by hand for the identity tail (steps 16 .. 23: the last conv2 steps,
+// conv3 of chunk 0 with its 8 identity loads requested in step 15 and its 8 stores behind step 19, conv1' of chunk 0 with the next
+// identity loads in step 20): stage DMAs count 2, everything younger than the awaited stage may be in flight.
+static_assert(BtResC64::NSTEP == 34 && BtResC128::NSTEP == 42 && BtDualC64::NSTEP == 42, "steps per tile");
+static_assert(BtResC64::wait_top(14) == 4 && BtResC64::wait_top(16) == 12 && BtResC64::wait_top(18) == 12 && BtResC64::wait_top(19) == 4,
+              "conv2 -> chunk 0");
+static_assert(BtResC64::wait_top(20) == 12 && BtResC64::wait_top(21) == 20 && BtResC64::wait_top(22) == 20 && BtResC64::wait_top(23) == 12,
+              "chunk pattern: conv1' steps behind the stores, the next chunk's conv3 steps behind the identity loads");
+static_assert(BtResC64::wait_top(0) == 20 && BtDualC64::wait_top(4) == 12 && BtDualC64::wait_top(6) == 4, "tile start; block-input loads of the DUAL tail in step 2");
+
 }  // namespace mpx
