@@ -197,6 +197,9 @@ int mpx_set_fusion(mpx_engine* h, int mask);
  * t1_*: conv2's input planes [B][56][56][64]; x_*: the block's identity planes [B][56][56][256] -- for a block with a
  * downsample branch (layer1.0) the BLOCK INPUT planes [B][56][56][64], the branch being K-concatenated as in
  * mpx_conv_dual_bn_act; out_*: block output [B][56][56][256]; next_*: the following conv1's output [B][56][56][64 or 128].
+ * For the block with the downsample branch t1_hi = t1_lo = NULL makes the launch compute t1 itself: the block's own
+ * `out = self.relu(self.bn1(self.conv1(x)))` (64 -> 64, 1x1) runs on the halo tile of the block input it has staged anyway, so
+ * layer1.0 is ONE launch with one read of its 64-channel input and neither t1 nor t2 ever in memory (what mpx_forward does).
  * All four plane pairs must be distinct buffers (workgroups read t1's halo while others write).  Same arithmetic as the
  * layer-by-layer path up to fp32 summation order.  mpx_forward takes this path by default. */
 int mpx_bottleneck_tail(mpx_engine* h, int i, const void* t1_hi, const void* t1_lo, const void* x_hi, const void* x_lo,

@@ -78,7 +78,7 @@ struct Op {
 // downsample branch) -> the next block's conv1.  Weights: conv2's and next1's packed planes as they are; conv3's (or the fused
 // conv3 | downsample planes') with columns [0,64) K-permuted into planes of its own.
 struct TailBlock {
-    int c2 = -1, c3 = -1, ds = -1, next1 = -1;
+    int c1 = -1, c2 = -1, c3 = -1, ds = -1, next1 = -1;     // c1: the block's own conv1 (runs inside the launch when the block has a downsample branch)
     half_t* w3p_hi = nullptr;
     half_t* w3p_lo = nullptr;
     bool ready = false;
@@ -302,15 +302,23 @@ int build_topology(mpx_engine* h) {
             for (size_t k = 0; k < blocks.size(); ++k) {
                 const BlockRec& R = blocks[k];
                 int T1 = T1c;
-                if (T1 < 0) {
+                // a tail with a downsample branch (layer1.0) runs its block's own conv1 too, on the patch of the block input: no conv1
+                // launch, no t1 tensor (in = BUF_NONE)
+#ifdef BT_NO_HEAD       // probe builds (tools/ab_lib.sh): layer1.0.conv1 stays a launch of its own
+                const bool whole = false;
+#else
+                const bool whole = tail_ok(k) && R.ds >= 0 && T1 < 0;
+#endif
+                if (T1 < 0 && !whole) {
                     T1 = pick({Xb});
                     out.push_back(Op{OP_CONV, R.c1, Xb, T1, BUF_NONE, 0, 0, BUF_NONE});
                 }
                 T1c = -100;
                 if (tail_ok(k)) {
                     TailBlock tb;
-                    tb.c2 = R.c2; tb.c3 = R.c3; tb.ds = R.ds; tb.next1 = blocks[k + 1].c1;
+                    tb.c1 = R.c1; tb.c2 = R.c2; tb.c3 = R.c3; tb.ds = R.ds; tb.next1 = blocks[k + 1].c1;
                     h->tails.push_back(tb);
+                    if (whole) T1 = BUF_NONE;
                     const int O = pick({Xb, T1}), Z = pick({Xb, T1, O});
                     Op o{OP_BTAIL, (int)h->tails.size() - 1, T1, O, Xb, 0, 0, BUF_NONE};
                     o.z = Z;
@@ -841,7 +849,7 @@ TailBlock* tail_of_conv3(mpx_engine* h, int c3) {
 bool tails_ready(const mpx_engine* h) {
     if (h->tails.empty()) return false;
     for (const TailBlock& tb : h->tails)
-        if (!tb.ready || !h->convs[tb.c2].loaded || !h->convs[tb.next1].loaded) return false;
+        if (!tb.ready || !h->convs[tb.c2].loaded || !h->convs[tb.next1].loaded || !h->convs[tb.c1].loaded) return false;
     return true;
 }
 
@@ -855,9 +863,17 @@ int launch_btail(mpx_engine* h, int ti, const half_t* t_hi, const half_t* t_lo, 
     const ConvLayer& N1 = h->convs[tb.next1];
     if (!tb.ready || !L2.loaded || !N1.loaded) return fail(h, MPX_E_STATE, "block tail %s: weights missing", L2.d.name);
     const bool dual = tb.ds >= 0;
+    const bool head = t_hi == nullptr;          // the block's own conv1 runs inside the launch, on the patch of the block input
+    if (head && !dual) return fail(h, MPX_E_ARG, "block tail %s: only a block with a downsample branch (64-channel input) can run its own conv1 in the launch", L2.d.name);
     BtParams p;
     std::memset(&p, 0, sizeof p);
-    p.t_hi = t_hi; p.t_lo = t_lo;
+    p.t_hi = head ? x_hi : t_hi; p.t_lo = head ? x_lo : t_lo;
+    if (head) {
+        const ConvLayer& L1 = h->convs[tb.c1];
+        if (!L1.loaded) return fail(h, MPX_E_STATE, "block tail %s: weights of %s missing", L2.d.name, L1.d.name);
+        if (!(L1.d.cin == BT_MID && L1.d.cout == BT_MID && L1.d.ksize == 1 && L1.d.stride == 1)) return fail(h, MPX_E_INTERNAL, "block tail: %s is not a 64 -> 64 1x1 conv", L1.d.name);
+        p.w0_hi = L1.w_hi; p.w0_lo = L1.w_lo; p.sc0 = L1.scale; p.sh0 = L1.shift;
+    }
     p.w2_hi = L2.w_hi; p.w2_lo = L2.w_lo; p.sc2 = L2.scale; p.sh2 = L2.shift;
     p.w3_hi = tb.w3p_hi; p.w3_lo = tb.w3p_lo;
     p.sc3 = dual ? L3.fscale : L3.scale; p.sh3 = dual ? L3.fshift : L3.shift;
@@ -877,7 +893,8 @@ int launch_btail(mpx_engine* h, int ti, const half_t* t_hi, const half_t* t_lo, 
     const long long resident = 2LL * h->num_cus;                       // two 80-KB workgroups per CU
     const unsigned grid = (unsigned)std::min<long long>(resident / 8 * 8, (n_tiles + 7) / 8 * 8);
     ProfScope ps(h, st, OP_CONV, tb.c2);
-    if (dual) hipLaunchKernelGGL(btail_f16x3_kernel<BtDualC64>, dim3(grid), dim3(256), BtDualC64::LDS, st, p);
+    if (head) hipLaunchKernelGGL(btail_f16x3_kernel<BtHeadC64>, dim3(grid), dim3(256), BtHeadC64::LDS, st, p);
+    else if (dual) hipLaunchKernelGGL(btail_f16x3_kernel<BtDualC64>, dim3(grid), dim3(256), BtDualC64::LDS, st, p);
     else if (N1.d.cout == 128) hipLaunchKernelGGL(btail_f16x3_kernel<BtResC128>, dim3(grid), dim3(256), BtResC128::LDS, st, p);
     else hipLaunchKernelGGL(btail_f16x3_kernel<BtResC64>, dim3(grid), dim3(256), BtResC64::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
@@ -1104,6 +1121,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtResC128>, hipFuncAttributeMaxDynamicSharedMemorySize, BtResC128::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtDualC64>, hipFuncAttributeMaxDynamicSharedMemorySize, BtDualC64::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)btail_f16x3_kernel<BtHeadC64>, hipFuncAttributeMaxDynamicSharedMemorySize, BtHeadC64::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
@@ -1388,7 +1407,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     // layer-by-layer kernels of those layers
     bool use_bt = h->fuse_bt && h->fuse_ds && tails_ready(h);
     for (const TailBlock& tb : h->tails)
-        for (int li : {tb.c2, tb.c3, tb.next1})
+        for (int li : {tb.c1, tb.c2, tb.c3, tb.next1})
             use_bt = use_bt && h->convs[li].tile == default_tile(h->convs[li].d);
     const std::vector<Op>& ops = use_bt ? h->ops_bt : h->ops;
     for (size_t oi = 0; oi < ops.size(); ++oi) {
@@ -1451,7 +1470,7 @@ int mpx_set_fusion(mpx_engine* h, int mask) {
 int mpx_bottleneck_tail(mpx_engine* h, int i, const void* t1_hi, const void* t1_lo, const void* x_hi, const void* x_lo,
                         void* out_hi, void* out_lo, void* next_hi, void* next_lo, int B, void* stream) {
     if (!h) return MPX_E_ARG;
-    if (B <= 0 || !t1_hi || !t1_lo || !x_hi || !x_lo || !out_hi || !out_lo || !next_hi || !next_lo)
+    if (B <= 0 || (t1_hi == nullptr) != (t1_lo == nullptr) || !x_hi || !x_lo || !out_hi || !out_lo || !next_hi || !next_lo)
         return fail(h, MPX_E_ARG, "bottleneck_tail: null planes or empty batch");
     int ti = -1;
     for (size_t k = 0; k < h->tails.size(); ++k)
@@ -1466,7 +1485,7 @@ int mpx_num_bottleneck_tails(const mpx_engine* h) { return h ? (int)h->tails.siz
 
 int mpx_bottleneck_tail_info(const mpx_engine* h, int k, int* conv2, int* conv3, int* downsample, int* next_conv1) {
     if (!h || k < 0 || k >= (int)h->tails.size()) return MPX_E_ARG;
-    if (conv2) *conv2 = h->tails[k].c2;
+    if (conv2) *conv2 = h->tails[k].c2;         // (the block's own conv1 is the layer in front of it)
     if (conv3) *conv3 = h->tails[k].c3;
     if (downsample) *downsample = h->tails[k].ds;
     if (next_conv1) *next_conv1 = h->tails[k].next1;

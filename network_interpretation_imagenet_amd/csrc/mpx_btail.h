@@ -43,8 +43,12 @@
 namespace mpx {
 
 struct BtParams {
-    const half_t* t_hi;      // conv2 input planes [B][H][W][64]
+    const half_t* t_hi;      // conv2 input planes [B][H][W][64] (HEAD: the block input planes, conv1 runs on the patch)
     const half_t* t_lo;
+    const half_t* w0_hi;     // HEAD only: the block's OWN conv1 (1x1, 64 -> 64), piece-major [>= 64][64]; then t_* = the block input
+    const half_t* w0_lo;
+    const float* sc0;
+    const float* sh0;
     const half_t* w2_hi;     // conv2 weights, piece-major [>= 64][576] (mpx_pack_conv_weights)
     const half_t* w2_lo;
     const float* sc2;
@@ -116,17 +120,21 @@ constexpr int BT_MID = 64, BT_OUT = 256;
 #define BT_ABL 0
 #endif
 
-template <bool DUAL_, int C1_>
+template <bool DUAL_, int C1_, bool HEAD_ = false>
 struct BtCfg {
     static constexpr bool DUAL = DUAL_;
     static constexpr int C1 = C1_;
+    static constexpr bool HEAD = HEAD_;                 // the block's own conv1 (64 -> 64, 1x1) runs on the patch first: layer1.0 whole
+    static_assert(!HEAD || DUAL, "the head conv1 has 64 input channels: only the first block of layer1");
+    static constexpr int NH = HEAD ? 2 : 0;             // its K steps (K = 64), in front of conv2's
     static constexpr int N2 = 18;                       // conv2 steps: 9 taps x 2 chunks of 32 channels
+    static constexpr int JC = NH + N2;                  // first step of the chunk phase
     static constexpr int S3 = DUAL ? 4 : 2;             // conv3 steps per output chunk (K = 64, + 64 of the downsample branch)
     static constexpr int H1 = C1 / 64;                  // 64-row blocks of conv1'
     static constexpr int S1 = 2 * H1;                   // conv1' steps per chunk
     static constexpr int SC = S3 + S1;
-    static constexpr int NSTEP = N2 + 4 * SC;
-    static constexpr int NVEC = 2 * (BT_MID + BT_OUT + (C1 ? C1 : 4));    // floats: sc2 sh2 sc3 sh3 sc1 sh1
+    static constexpr int NSTEP = NH + N2 + 4 * SC;
+    static constexpr int NVEC = 2 * (BT_MID + BT_OUT + (C1 ? C1 : 4)) + (HEAD ? 2 * BT_MID : 0);    // floats: sc2 sh2 sc3 sh3 sc1 sh1 (sc0 sh0)
     static constexpr int LDS = BT_OFF_RING + BT_NRING * BT_STAGE;
     static_assert(NVEC * 4 <= BT_OFF_PATCH, "vectors overflow their LDS area");
     static_assert(C1 == 64 || C1 == 128, "conv1' has 64 or 128 output channels");
@@ -137,10 +145,10 @@ struct BtCfg {
     static constexpr int JX = 2;                        // DUAL: step behind whose stage the 8 block-input fragment loads are issued
     static constexpr int pre(int j) {                   // loads issued right behind the stage of step j
         j = mod(j);
-        if (DUAL) return j == JX ? 8 : 0;
-        if (j == N2 - 3) return 8;                                          // identity lines of chunk 0
+        if (DUAL) return (!HEAD && j == JX) ? 8 : 0;                        // HEAD reads the block input fragments from the patch
+        if (j == JC - 3) return 8;                                          // identity lines of chunk 0
         for (int c = 1; c < 4; ++c)
-            if (j == N2 + (c - 1) * SC + S3 + (H1 == 2 ? S1 - 1 : 0)) return 8;   // ... of chunk c: in the first (C1 = 128: last,
+            if (j == JC + (c - 1) * SC + S3 + (H1 == 2 ? S1 - 1 : 0)) return 8;   // ... of chunk c: in the first (C1 = 128: last,
                                                                             // the registers are short) conv1' step of chunk c-1
         return 0;
     }
@@ -148,7 +156,7 @@ struct BtCfg {
         j = mod(j);
         int n = 0;
         for (int c = 0; c < 4; ++c)
-            if (j == N2 + c * SC + S3 - 1) n += 8;                          // `out` lines of chunk c
+            if (j == JC + c * SC + S3 - 1) n += 8;                          // `out` lines of chunk c
         if (j == NSTEP - 1) n += 8 * H1;                                    // t1' lines
         return n;
     }
@@ -158,7 +166,7 @@ struct BtCfg {
     static constexpr bool late_a(int j) {
         if (H1 != 2) return false;
         for (int c = 0; c < 4; ++c)
-            if (j == N2 + c * SC + S3 - 1) return true;
+            if (j == JC + c * SC + S3 - 1) return true;
         return false;
     }
     // top of step j: the stage of step j (issued first thing in step j-3) has landed; everything behind it may be in flight
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     constexpr bool DUAL = C::DUAL;
-    constexpr int C1 = C::C1, N2 = C::N2, S3 = C::S3, S1 = C::S1, SC = C::SC, H1 = C::H1, NSTEP = C::NSTEP;
+    constexpr bool HEAD = C::HEAD;
+    constexpr int C1 = C::C1, N2 = C::N2, NH = C::NH, JC = C::JC, S3 = C::S3, S1 = C::S1, SC = C::SC, H1 = C::H1, NSTEP = C::NSTEP;
     constexpr unsigned OOB = 0x80000000u;
 
     const int tid = threadIdx.x;
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     char* const stg = patch + wave * 8192;                             // wave-private staging (inside the patch bytes)
     float* const vec = (float*)(smem + BT_OFF_VEC);
     constexpr int V_SC2 = 0, V_SH2 = BT_MID, V_SC3 = 2 * BT_MID, V_SH3 = 2 * BT_MID + BT_OUT, V_SC1 = 2 * BT_MID + 2 * BT_OUT,
-                  V_SH1 = V_SC1 + (C1 ? C1 : 4);
+                  V_SH1 = V_SC1 + (C1 ? C1 : 4), V_SC0 = V_SH1 + (C1 ? C1 : 4), V_SH0 = V_SC0 + BT_MID;
 
     // scale / shift vectors -> LDS (published by the first barrier below)
     for (int i = tid; i < C::NVEC; i += 256) {
@@ -217,10 +226,14 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         else if (i < V_SC1) v = p.sh3[i - V_SH3];
         else if (C1 && i < V_SH1) v = p.sc1[i - V_SC1];
         else if (C1 && i < V_SH1 + C1) v = p.sh1[i - V_SH1];
+        else if (HEAD && i >= V_SC0 && i < V_SH0) v = p.sc0[i - V_SC0];
+        else if (HEAD && i >= V_SH0) v = p.sh0[i - V_SH0];
         vec[i] = v;
     }
 
     // ---- weight stream --------------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t w0h = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? p.w0_hi : p.w2_hi), 0, 64 * 64 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w0l = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? p.w0_lo : p.w2_lo), 0, 64 * 64 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2_hi, 0, 64 * 576 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2_lo, 0, 64 * 576 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3_hi, 0, BT_OUT * S3 * 64, 0x00020000);
@@ -232,12 +245,16 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
     auto issue_stage = [&](auto js_tag, int slot) {
         constexpr int JS = decltype(js_tag)::value;
         char* const d = ring + slot * BT_STAGE + wave * 1024;
-        if (JS < N2) {
-            const int soff = (wave * 18 + JS) * 1024;
+        if (JS < NH) {                                  // the head conv1: rows [16 wave, +16), K step JS of 2
+            const int soff = (wave * 2 + JS) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w0h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w0l, MPX_LDS_PTR(d + 4096), 16, w_lane, soff, 0, 0);
+        } else if (JS < JC) {
+            const int soff = (wave * 18 + JS - NH) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w2h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w2l, MPX_LDS_PTR(d + 4096), 16, w_lane, soff, 0, 0);
         } else {
-            constexpr int cc = (JS - N2) / SC, r = (JS - N2) % SC;
+            constexpr int cc = (JS - JC) / SC, r = (JS - JC) % SC;
             if (r < S3) {
                 const int soff = ((4 * cc + wave) * S3 + r) * 1024;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w3h, MPX_LDS_PTR(d), 16, w_lane, soff, 0, 0);
@@ -395,11 +412,11 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                     read_a1((sbase + J + 1) & 3, An, i >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if ((i & 1) == 0 && i >= 16 && J + 1 < N2) {
-                    read_patch1(std::integral_constant<int, (J + 1 < N2 ? J + 1 : 0)>{}, fb[(J + 1) & 1], (i - 16) >> 1);
+                if ((i & 1) == 0 && i >= 16 && J + 1 > NH && J + 1 < JC) {      // (the first conv2 step of HEAD reads them behind the t1 writes)
+                    read_patch1(std::integral_constant<int, (J + 1 > NH && J + 1 < JC ? J + 1 - NH : 0)>{}, fb[(J + 1) & 1], (i - 16) >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if ((i & 1) == 0 && i >= 16 && J >= N2 && (J - N2) % SC == S3 + H1 - 1) {
+                if ((i & 1) == 0 && i >= 16 && J >= JC && (J - JC) % SC == S3 + H1 - 1) {
                     // the step before conv1's second K step of this chunk: its B fragments (written by the chunk epilogue)
                     const int q = (i - 16) >> 1, b = q & 1, plane = q >> 1;
                     const h8 f = *(const h8*)(stg + (b * 4 + 2 + plane) * 1024 + sb_off);
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                             }
                         }
                     } else {
-                        issue_identity(J < N2 ? 0 : (J - N2) / SC + 1);
+                        issue_identity(J < JC ? 0 : (J - JC) / SC + 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -437,8 +454,94 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) read_a1(sbase & 3, fa[0], i);
         }
+        if constexpr (HEAD) {
+            // ================= the block's own conv1 on the patch (layer1.0 whole: the patch holds the block INPUT) ====================
+            // The downsample branch's operand = the block input at this wave's own pixels: B fragments from the patch (tap (1,1)),
+            // before conv1 overwrites it.  (The step barriers below order these reads of every wave before any write.)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) read_patch1(std::integral_constant<int, 0>{}, fb[0], i);
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    x0h[kk][b] = *(const h8*)(patch + (kk * 2 + 0) * BT_BLK + pb_off[b][1] + 1024);
+                    x0l[kk][b] = *(const h8*)(patch + (kk * 2 + 1) * BT_BLK + pb_off[b][1] + 1024);
+                }
+            // conv1 is pointwise: t1 of every patch pixel, in place.  Patch row r (16 pixels = one fragment) belongs to wave r % 4:
+            // rows w and w+4 in the regular step (two fragments), row w+8 (waves 0 and 1 only) in 12 extra MFMAs on the same weight
+            // fragments, which stay in fa[J & 1] until the next step's read-ahead overwrites them.
+            const int h_off = lp * 64 + ((lg ^ (((lp >> 2) & 1) << 1)) << 4);       // this lane's 16-B chunk of its pixel's row
+            f4 acch[4][2], accx[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acch[a][0] = acch[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+                accx[a] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            auto head_step = [&](auto k_tag) {
+                constexpr int kk = decltype(k_tag)::value;
+                h8 bh[2], bl[2], xh, xl;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    bh[b] = *(const h8*)(patch + (kk * 2 + 0) * BT_BLK + (wave + 4 * b) * 1024 + h_off);
+                    bl[b] = *(const h8*)(patch + (kk * 2 + 1) * BT_BLK + (wave + 4 * b) * 1024 + h_off);
+                }
+                if (wave < 2) {
+                    xh = *(const h8*)(patch + (kk * 2 + 0) * BT_BLK + (wave + 8) * 1024 + h_off);
+                    xl = *(const h8*)(patch + (kk * 2 + 1) * BT_BLK + (wave + 8) * 1024 + h_off);
+                }
+                step(std::integral_constant<int, kk>{}, acch, bh, bl);
+                if (wave < 2) {
+                    const FragA& A = fa[kk & 1];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        accx[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], xl, accx[a], 0, 0, 0);
+                        accx[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo[a], xh, accx[a], 0, 0, 0);
+                        accx[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], xh, accx[a], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            head_step(std::integral_constant<int, 0>{});
+            head_step(std::integral_constant<int, 1>{});
+            // t1 = relu(acc * scale0 + shift0), ZERO outside the image (conv2's padding), split, written over the block input: D layout
+            // (lane = pixel, 4 consecutive channels per register quad) -> the 8-B piece (a & 1) * 32 + 8 g of the pixel's row of chunk a >> 1
+            auto write_t1 = [&](const f4 (&v4)[4], int r) {
+                const int iy = y0 - 1 + r, ix = x0 - 1 + lp;
+                const float keep = ((iy | (p.H - 1 - iy) | ix | (p.W - 1 - ix)) < 0) ? 0.f : 1.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f4 sc = *(const f4*)(vec + V_SC0 + a * 16 + 4 * lg);
+                    const f4 sh = *(const f4*)(vec + V_SH0 + a * 16 + 4 * lg);
+                    const f4 v = v4[a] * sc + sh;
+                    h4 hi4, lo4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = fmaxf(v[j], 0.f) * keep;
+                        const half_t hi = (half_t)t;
+                        hi4[j] = hi;
+                        lo4[j] = (half_t)__builtin_fmaf((float)hi, -one, t);
+                    }
+                    char* const d = patch + ((a >> 1) * 2) * BT_BLK + (r * 16 + lp) * 64 + ((((a & 1) * 2 + (lg >> 1)) ^ (((lp >> 2) & 1) << 1)) << 4) + (lg & 1) * 8;
+                    *(h4*)d = hi4;
+                    *(h4*)(d + BT_BLK) = lo4;
+                }
+            };
+            {
+                f4 v0[4], v1[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    v0[a] = acch[a][0];
+                    v1[a] = acch[a][1];
+                }
+                write_t1(v0, wave);
+                write_t1(v1, wave + 4);
+                if (wave < 2) write_t1(accx, wave + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // t1 of every patch row is in place
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) read_patch1(std::integral_constant<int, 0>{}, fb[NH & 1], i);
 
         // ================= conv2: 18 steps over the resident patch ==========================================================
         f4 acc2[4][2];
@@ -446,9 +549,9 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc2[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
-        auto conv2_step = [&](auto j_tag) {
-            constexpr int J = decltype(j_tag)::value;
-            step(j_tag, acc2, fb[J & 1].hi, fb[J & 1].lo);
+        auto conv2_step = [&](auto k_tag) {     // conv2's K step k = step NH + k of the tile
+            constexpr int J = NH + decltype(k_tag)::value;
+            step(std::integral_constant<int, J>{}, acc2, fb[J & 1].hi, fb[J & 1].lo);
         };
         conv2_step(std::integral_constant<int, 0>{});
         conv2_step(std::integral_constant<int, 1>{});
@@ -499,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
         // ================= 4 output chunks of 64 channels =======================================================================
         auto chunk = [&](auto c_tag) {
             constexpr int c = decltype(c_tag)::value;
-            constexpr int J0 = N2 + c * SC;
+            constexpr int J0 = JC + c * SC;
             f4 acc3[4][2];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -650,6 +753,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
 typedef BtCfg<false, 64> BtResC64;      // layer1.1 / layer1.2 tails: identity = the trunk, next conv1 256 -> 64
 typedef BtCfg<false, 128> BtResC128;    // layer1's last block: next conv1 = layer2.0.conv1, 256 -> 128
 typedef BtCfg<true, 64> BtDualC64;      // layer1.0: downsample branch K-concatenated, next conv1 256 -> 64
+typedef BtCfg<true, 64, true> BtHeadC64; // layer1.0 whole: its own conv1 runs on the patch of the block input first
 
 // The wait immediates, checked against the program written out by hand for the identity tail (steps 16 .. 23: the last conv2 steps,
 // conv3 of chunk 0 with its 8 identity loads requested in step 15 and its 8 stores behind step 19, conv1' of chunk 0 with the next

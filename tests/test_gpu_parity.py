@@ -336,13 +336,15 @@ def _round_split(x64):
     return merge(hi, lo).double()
 
 
-@pytest.mark.parametrize("k,batch", [(0, 2), (1, 1), (1, 3), (2, 2), (1, 41), (0, 23), (2, 37)])
-def test_bottleneck_tail_vs_fp64_chain(eng101, k, batch):
+@pytest.mark.parametrize("k,batch,whole", [(0, 2, False), (1, 1, False), (1, 3, False), (2, 2, False), (1, 41, False), (0, 23, False), (2, 37, False),
+                                           (0, 1, True), (0, 3, True), (0, 41, True)])
+def test_bottleneck_tail_vs_fp64_chain(eng101, k, batch, whole):
     """mpx_bottleneck_tail (csrc/mpx_btail.h): conv2 -> conv3 + identity (k = 0: + the K-concatenated downsample branch) -> the next
     block's conv1 (k = 2: layer2.0.conv1, 128 channels) in ONE launch, against the fp64 chain of the same three (four) layers on
     the same split inputs, with t2 and the block output rounded to hi + lo where the layer-by-layer path stores them.  One image
     is 28 tiles; 23 .. 41 images are 644 .. 1148 tiles on 512 resident workgroups: tile boundaries, the weight ring running on
-    across tiles, workgroups with one, two and three tiles."""
+    across tiles, workgroups with one, two and three tiles.  whole (layer1.0 only): t1 planes = NULL -- the launch also runs the
+    block's own conv1 on the patch of the block input (what mpx_forward does), checked against the chain with that conv in front."""
     sd = synth.make_state_dict("resnet101")
     tails = eng101.bottleneck_tails()
     assert len(tails) == 3
@@ -358,12 +360,17 @@ def test_bottleneck_tail_vs_fp64_chain(eng101, k, batch):
     xh, xl = split(x.to(dev))
     nan = lambda c: torch.full((batch + 1, 56, 56, c), float("nan"), dtype=torch.float16, device=dev)
     oh, ol, zh, zl = nan(256), nan(256), nan(dn.cout), nan(dn.cout)
-    rc = eng101._lib.mpx_bottleneck_tail(eng101._h, c2, _p(th), _p(tl), _p(xh), _p(xl), _p(oh), _p(ol), _p(zh), _p(zl), batch, eng101._stream())
+    rc = eng101._lib.mpx_bottleneck_tail(eng101._h, c2, None if whole else _p(th), None if whole else _p(tl), _p(xh), _p(xl), _p(oh), _p(ol),
+                                         _p(zh), _p(zl), batch, eng101._stream())
     _lib.check(eng101._h, rc, "mpx_bottleneck_tail")
     torch.cuda.synchronize()
     assert torch.isnan(oh[batch]).all() and torch.isnan(zl[batch]).all()           # nothing written past the batch
 
     t1u, xu = merge(th, tl).cpu().double().permute(0, 3, 1, 2), merge(xh, xl).cpu().double().permute(0, 3, 1, 2)
+    if whole:
+        d1 = eng101.layers[c2 - 1]
+        assert d1.name.decode() == "layer1.0.conv1"
+        t1u = _round_split(F.relu(_conv_bn_fp64(sd, d1, xu)))
     t2 = _round_split(F.relu(_conv_bn_fp64(sd, d2, t1u)))
     ident = _conv_bn_fp64(sd, eng101.layers[ds], xu) if ds >= 0 else xu
     out = F.relu(_conv_bn_fp64(sd, d3, t2) + ident)
@@ -382,6 +389,8 @@ def test_bottleneck_tail_argument_errors(eng101, eng18, dev):
     c2 = eng101.bottleneck_tails()[1][0]
     assert lib.mpx_bottleneck_tail(h, c2 + 1, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 1, None) == -1     # not a conv2 of a tail
     assert lib.mpx_bottleneck_tail(h, c2, _p(t), _p(t), _p(t), None, _p(t), _p(t), _p(t), _p(t), 1, None) == -1
+    assert lib.mpx_bottleneck_tail(h, c2, None, None, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 1, None) == -1       # no t1: only layer1.0 can compute it
+    assert lib.mpx_bottleneck_tail(h, c2, _p(t), None, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 1, None) == -1       # half a plane pair
     assert lib.mpx_bottleneck_tail(h, c2, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 0, None) == -1
     assert b"bottleneck_tail" in lib.mpx_last_error(h)
     assert eng18.bottleneck_tails() == []              # basic blocks have no such tail

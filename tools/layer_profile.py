@@ -94,10 +94,11 @@ for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
 tails = eng.bottleneck_tails()
 if tails and not os.environ.get("MPX_NO_FUSION") and os.environ.get("MPX_FUSION_MASK", "3") == "3":
     names = [d.name.decode() for d in eng.layers]
-    print("-- block tails (one launch each: conv2 -> conv3 + identity -> next conv1; the time is booked on the conv2 row) --")
+    print("-- block tails (one launch each: conv2 -> conv3 + identity -> next conv1; the time is booked on the conv2 row; the tail with the"
+          " downsample branch runs its block's own conv1 too) --")
     for c2, c3, ds, n1 in tails:
-        print("  %-16s + %s%s + %-16s %8.3f ms" % (names[c2], names[c3], (" + " + names[ds]) if ds >= 0 else "", names[n1],
-                                                    prof["per_conv_ms"][c2] / reps))
+        print("  %s%-16s + %s%s + %-16s %8.3f ms" % ((names[c2 - 1] + " + ") if ds >= 0 else "", names[c2], names[c3],
+                                                      (" + " + names[ds]) if ds >= 0 else "", names[n1], prof["per_conv_ms"][c2] / reps))
 layer1 = sum(ms for d, ms in zip(eng.layers, prof["per_conv_ms"]) if d.name.startswith(b"layer1.") or d.name == b"layer2.0.conv1") / reps
 print("layer1 (+ layer2.0.conv1): %.3f ms/batch" % layer1)
 allfl = eng.flops_per_forward * batch

@@ -64,6 +64,19 @@ for k, (c2, c3, ds, n1) in enumerate(eng.bottleneck_tails()):
         _lib.check(eng._h, eng._lib.mpx_conv_bn_act(eng._h, n1, p(rh), p(rl), None, None, p(qh), p(ql), None, batch, None), "conv1")
         torch.cuda.synchronize()
         oh, ol, zh, zl = outs[0]
+        if ds >= 0:
+            # the whole block in one launch (t1 = NULL: conv1 runs on the patch of the block input) against conv1 -> the same tail
+            t1h = torch.empty(batch, 56, 56, 64, dtype=torch.float16, device=dev); t1l = torch.empty_like(t1h)
+            _lib.check(eng._h, eng._lib.mpx_conv_bn_act(eng._h, c2 - 1, p(xh), p(xl), None, None, p(t1h), p(t1l), None, batch, None), "conv1")
+            a_ = [torch.full_like(t, float("nan")) for t in (oh, ol, zh, zl)]
+            b_ = [torch.full_like(t, float("nan")) for t in (oh, ol, zh, zl)]
+            _lib.check(eng._h, eng._lib.mpx_bottleneck_tail(eng._h, c2, p(t1h), p(t1l), p(xh), p(xl), *[p(t) for t in a_], batch, None), "tail")
+            for rep in range(3):
+                _lib.check(eng._h, eng._lib.mpx_bottleneck_tail(eng._h, c2, None, None, p(xh), p(xl), *[p(t) for t in b_], batch, None), "whole")
+                torch.cuda.synchronize()
+                for u, v in ((a_[0].float() + a_[1].float(), b_[0].float() + b_[1].float()), (a_[2].float() + a_[3].float(), b_[2].float() + b_[3].float())):
+                    assert not torch.isnan(v).any()
+                    worst = max(worst, float((u - v).abs().max() / u.abs().max().clamp_min(1.0)))
         for got, want in (((oh, ol), (rh, rl)), ((zh, zl), (qh, ql))):
             a, b = got[0].float() + got[1].float(), want[0].float() + want[1].float()
             assert not torch.isnan(a).any()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time one block tail (mpx_bottleneck_tail, csrc/mpx_btail.h) on random planes.  usage: python tools/tail_bench.py [k] [batch] [reps]"""
+"""Time one block tail (mpx_bottleneck_tail, csrc/mpx_btail.h) on random planes.  usage: python tools/tail_bench.py [k] [batch] [reps]
+(tail 0 = layer1.0 runs as mpx_forward runs it: whole, its own conv1 inside the launch)"""
 import ctypes as C
 import os
 import sys
@@ -34,7 +35,8 @@ th, tl = planes(64)
 xh, xl = planes(64 if ds >= 0 else 256)
 oh = torch.empty(batch, 56, 56, 256, dtype=torch.float16, device=dev); ol = torch.empty_like(oh)
 zh = torch.empty(batch, 56, 56, c1, dtype=torch.float16, device=dev); zl = torch.empty_like(zh)
-run = lambda: _lib.check(eng._h, eng._lib.mpx_bottleneck_tail(eng._h, c2, p(th), p(tl), p(xh), p(xl), p(oh), p(ol), p(zh), p(zl), batch, None), "tail")
+whole = ds >= 0
+run = lambda: _lib.check(eng._h, eng._lib.mpx_bottleneck_tail(eng._h, c2, None if whole else p(th), None if whole else p(tl), p(xh), p(xl), p(oh), p(ol), p(zh), p(zl), batch, None), "tail")
 for _ in range(2):
     run()
 torch.cuda.synchronize()
@@ -45,7 +47,7 @@ for _ in range(reps):
 t1.record()
 torch.cuda.synchronize()
 ms = t0.elapsed_time(t1) / reps
-units = (1.43 + (1 if ds >= 0 else 4) + 4 + c1 / 64) * 64 * 4 * batch * 56 * 56
+units = (1.43 + (0 if whole else 4) + 4 + c1 / 64) * 64 * 4 * batch * 56 * 56
 print("tail %d (%s, next conv1 %d) batch %d: %.3f ms per launch; %.1f GB of HBM traffic by the plan = %.2f TB/s" % (
     k, "downsample branch" if ds >= 0 else "identity", c1, batch, ms, units / 1e9, units / ms / 1e9))
 eng.close()
