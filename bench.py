@@ -36,9 +36,12 @@ def parse():
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--images", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--masks", type=int, default=512, help="masks per image")
-    ap.add_argument("--images-per-forward", type=int, default=4,
-                    help="images whose masks share one forward batch (batch = this x masks; larger batches fill "
-                         "256 CUs with fewer partial rounds of tiles)")
+    ap.add_argument("--images-per-forward", type=int, default=0,
+                    help="forward batch = this x masks (0 = --forward-batch decides)")
+    ap.add_argument("--forward-batch", type=int, default=0,
+                    help="slots per forward batch; the mask rows of consecutive images are packed into such batches.  0 = the "
+                         "largest batch <= 2400 that cuts the 14x14 maps into WHOLE rounds of tiles over the 256 CUs "
+                         "(engine.whole_round_batch: 2340; at 2048 the last round of the 3x3 and reducing 1x1 layers is 1/8 full)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
@@ -48,14 +51,25 @@ def parse():
 def pmc_traffic(arch, batch):
     """HBM bytes of the conv kernels per forward batch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
     cannot be read from inside the process) -> (bytes per forward batch, file name); (None, None) unless a profile of this arch
-    and forward batch exists."""
+    exists.  A file taken at another forward batch is scaled by the batch ratio (activation bytes are proportional to the batch,
+    the 0.18 GB of weights are not: the source string says so)."""
     import glob
+    best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")), reverse=True):
         with open(path) as fh:
             j = json.load(fh)
-        if j.get("forward_batch") == batch and arch == j.get("arch", "resnet101"):
-            return j["write_bytes_per_batch"] + j["fetch_corrected_bytes_per_batch_guide_x2"], os.path.relpath(path, ROOT)
-    return None, None
+        if arch != j.get("arch", "resnet101"):
+            continue
+        if best is None or (j.get("forward_batch") == batch and best[0].get("forward_batch") != batch):
+            best = (j, path)
+    if best is None:
+        return None, None
+    j, path = best
+    total = j["write_bytes_per_batch"] + j["fetch_corrected_bytes_per_batch_guide_x2"]
+    name = os.path.relpath(path, ROOT)
+    if j["forward_batch"] != batch:
+        return total * batch / j["forward_batch"], "%s (measured at forward batch %d, scaled by %d/%d)" % (name, j["forward_batch"], batch, j["forward_batch"])
+    return total, name
 
 
 def _cpu_model():
@@ -129,10 +143,14 @@ def main():
     _lib.load()
     from network_interpretation_imagenet_amd.engine import MaskedForwardEngine
 
-    n_img, n_mask, ipf = args.images, args.masks, args.images_per_forward
-    if n_img % ipf:
-        raise SystemExit("--images must be a multiple of --images-per-forward")
-    batch = ipf * n_mask
+    from network_interpretation_imagenet_amd.engine import whole_round_batch
+    n_img, n_mask = args.images, args.masks
+    if args.images_per_forward:
+        batch = args.images_per_forward * n_mask
+    else:
+        batch = args.forward_batch or whole_round_batch(2400)
+    batch = min(batch, n_img * n_mask)
+    batches_per_step = n_img * n_mask / batch          # forward batches per step (the last one of a step may be partial)
     sd = synth.make_state_dict(args.arch)
     eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank).load_state_dict(sd)
     # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
@@ -191,17 +209,18 @@ def main():
         dt = float(t.item())
     assert out.numel() == total and bool(torch.isfinite(out).all())
     # per-kernel durations: ONE more step of the same work after the timed region, every launch bracketed by HIP events
-    # on its stream (engine profile pool); bounded to the first 32 forward batches of the step
+    # on its stream (engine profile pool)
     prof = {"ms": {}, "launches": {}}
-    batches_profiled = 0
+    batches_profiled = forwards_profiled = 0
     if rank == 0:
-        step_imgs = min(n_img, 32 * ipf)
+        step_imgs = n_img
         rows = step_imgs * n_mask
         eng.profile(True)
         eng.score_packed(img_list[:step_imgs], seg, onoff_list[:step_imgs], label_flat[:rows], scores.view(-1)[:rows], preds.view(-1)[:rows])
         eng.profile(False)
         prof = eng.collect_profile()
-        batches_profiled = step_imgs // ipf
+        batches_profiled = rows / batch
+        forwards_profiled = -(-rows // batch)
         torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -222,7 +241,7 @@ def main():
                         "frac": achieved / PEAK_F16_MFMA_TFLOPS,
                         # HBM bytes per conv launch = PMC bytes of the conv kernels per forward batch / conv launches per batch (a
                         # launch = one layer; 26 of them split their last round off into a second, small kernel dispatch)
-                        "traffic": (traffic_per_batch / (conv_n / batches_profiled)) if traffic_per_batch else None,
+                        "traffic": (traffic_per_batch / (conv_n / forwards_profiled)) if traffic_per_batch else None,
                         # NOT measured in this run: PMC counters need rocprofv3; the file holds the per-batch bytes of the same forward
                         "traffic_source": traffic_source, "traffic_bytes_per_forward_batch": traffic_per_batch,
                         "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel (all conv launches)", "launches": conv_n,
@@ -231,9 +250,9 @@ def main():
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)
                         "f16x3_ceiling": F16X3_CEILING_TFLOPS, "frac_of_f16x3_ceiling": achieved / F16X3_CEILING_TFLOPS,
                         "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,
-                        "measured": "HIP events around every launch of one extra step after the timed region (%d forward batches)" % int(batches_profiled),
+                        "measured": "HIP events around every launch of one extra step after the timed region (%.2f forward batches of %d)" % (batches_profiled, batch),
                         "conv_ms_per_batch": conv_ms / max(batches_profiled, 1),
-                        "timed_region_gpu_ms_per_batch": gpu_ms_timed / (args.steps * (n_img // ipf)),
+                        "timed_region_gpu_ms_per_batch": gpu_ms_timed / (args.steps * batches_per_step),
                         "other_kernels_ms_per_batch": {k: v / max(batches_profiled, 1) for k, v in prof["ms"].items() if k != "conv"}}
         line = {
             "metric": "masked-forward-passes/sec (224x224, %s)" % args.arch,

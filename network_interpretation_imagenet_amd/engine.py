@@ -26,6 +26,20 @@ ARCH_IDS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnet101": 101, "r
             "mnist_net": 1, "cifar_resnet20": 2020, "cifar_resnet56": 2056, "cifar_resnet110": 2110}
 
 
+COMPUTE_UNITS = 256        # MI355X
+ROUND_PIXELS_14 = 256      # pixels per tile of the kernels that run ONE workgroup per CU on the 14x14 maps (mpx_conv3p.h, mpx_conv256.h)
+
+
+def whole_round_batch(limit):
+    """Largest forward batch <= `limit` whose 14x14 maps cut into whole rounds of 256-pixel tiles over the 256 CUs
+    (334.37 images per round).  The 3x3 patch kernel and the 256x256 tile keep one workgroup per CU, so a batch just ABOVE a
+    whole number of rounds pays a whole extra round on the stage that holds 2/3 of an ImageNet ResNet's time: measured on
+    ResNet-101 (tools/batch_sweep.sh, profiles/r03_batch_sweep.txt) 44.8 us of conv time per masked image at 2006 / 2340 /
+    2674 / 3009 against 45.6-45.9 at 2010 and 2048.  Returns `limit` itself below one round."""
+    rounds = int(limit) * 196 // (COMPUTE_UNITS * ROUND_PIXELS_14)
+    return (rounds * COMPUTE_UNITS * ROUND_PIXELS_14) // 196 if rounds >= 1 else int(limit)
+
+
 class BasePredictionWrong(Exception):
     """The unmasked prediction differs from the label; the reference only defines the scorer when
     it is correct (generate_gp_training_data_imagenet.py:215,269-273;

@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.build()"
 cp network_interpretation_imagenet_amd/libmpx.so /tmp/libmpx_A.so; cp network_interpretation_imagenet_amd/libmpx.so.sha256 /tmp/libmpx_A.sha256
 ( cd network_interpretation_imagenet_amd/csrc && ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $FLAGS -o /tmp/libmpx_B.so mpx_api.hip )
 run() { cp /tmp/libmpx_$1.so network_interpretation_imagenet_amd/libmpx.so; cp /tmp/libmpx_A.sha256 network_interpretation_imagenet_amd/libmpx.so.sha256
-        python tools/layer_profile.py $ARCH $B $REPS > gpurun_out/ab_$1_$2.txt 2>&1; echo "== build $1 (run $2)"; grep -E "64->64    k1|conv total|layer1\.|layer1 \(" gpurun_out/ab_$1_$2.txt | cut -c1-90; }
+        python tools/layer_profile.py $ARCH $B $REPS > gpurun_out/ab_$1_$2.txt 2>&1; echo "== build $1 (run $2)"; grep -E "k3 s1 out14|256->1024|1024->256|conv total" gpurun_out/ab_$1_$2.txt | cut -c1-90; }
 mkdir -p gpurun_out
 run A 1; run B 1; run A 2; run B 2
 cp /tmp/libmpx_A.so network_interpretation_imagenet_amd/libmpx.so
