@@ -3,6 +3,7 @@
 #include "../../include/mpx.h"
 #include "mpx_kernels.h"
 #include "mpx_conv3p.h"
+#include "mpx_conv3pp.h"
 #include "mpx_conv256.h"
 #include "mpx_convx.h"
 #include "mpx_btail.h"
@@ -626,6 +627,37 @@ int launch_conv_patch(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipS
     return 0;
 }
 
+// persistent patch kernel (mpx_conv3pp.h, tile id 12): the patch kernel's layers with cout >= 128 and no residual whose LDS image leaves 1 KB for the
+// cout tile's scale / shift vectors; a launch with fewer tiles than one grid unit runs on the patch kernel itself (same bits)
+template <class PC>
+bool patchp_fits(const mpx_conv_desc& d) {
+    return d.cout >= 128 && !d.residual && patch_fits<PC>(d) && PatchPersistent<PC>::lds_bytes(patch_rows_needed(d.hin, PC::TP)) <= kLdsLimit;
+}
+
+bool patchp_eligible(const mpx_conv_desc& d) { return patchp_fits<PatchTile0>(d) || patchp_fits<PatchTile2>(d); }
+
+template <class PC>
+int launch_conv_patchp(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipStream_t st) {
+    p.n_tiles_c = (p.cout + PC::TC - 1) / PC::TC;
+    if (p.n_tiles_c * PC::TC > d.cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    p.patch_rows = patch_rows_needed(d.hin, PC::TP);
+    const int lds = PatchPersistent<PC>::lds_bytes(p.patch_rows);
+    const long long n_tiles_p = ((long long)p.M + PC::TP - 1) / PC::TP;
+    const long long total = n_tiles_p * p.n_tiles_c;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    // one workgroup per CU; the grid is a multiple of 8 (XCD classes) and of n_tiles_c (a workgroup keeps its cout tile)
+    long long grid = h->num_cus;
+    if (total < grid) grid = total;
+    const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
+    grid = grid / unit * unit;
+    // (the kernel divides pixel and padded-pixel indices with a float reciprocal: exact below 2^23)
+    const long long padded = (long long)(p.M / (d.hin * d.hin) + 2) * (d.hin + 2) * (d.hin + 2);
+    if (grid <= 0 || p.r_hi || padded >= (1 << 23)) return launch_conv_patch<PC>(h, p, d, st);
+    hipLaunchKernelGGL(conv3x3pp_f16x3_kernel<PC>, dim3((unsigned)grid), dim3(PC::NT), lds, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Default variant per layer, from tools/tile_sweep.sh and in-network tools/layer_profile.py runs on MI355X at
 // batch 2048: cout <= 64 layers take a 64-row tile (no zero-padded MFMA rows); of the rest, the 128x128 tile
 // with two workgroups per CU wins on every 1x1 shape by 5-15 % (one workgroup's HBM-bound epilogue overlaps the
@@ -634,6 +666,9 @@ int launch_conv_patch(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipS
 // the patch kernel (mpx_conv3p.h, tile id 6).  Every tile stays selectable.
 int default_tile(const mpx_conv_desc& d) {
     if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;       // (the patch kernel is 10 % slower than tile 1 on 64->64 in the network)
+    // ... as one persistent workgroup per CU (mpx_conv3pp.h) where the layer has no residual operand: in the network (batch 2340,
+    // A/B in one call) 128->128 on 28x28 3.89 -> 3.67 ms, 256->256 on 14x14 24.65 -> 24.49 ms per batch; 7x7 maps lose 1 % (2.29 -> 2.32)
+    if (patchp_eligible(d) && d.hout >= 14) return 12;
     if (patch_eligible(d)) return 6;                      // 3x3 stride 1 on 28x28 / 14x14 / 7x7 maps: -10..18 % against tile 0
     if (d.ksize == 3) return 0;
     // expanding 1x1 layers (short K, long epilogue): four waves per SIMD cover the epilogue better, -2..4 % in the
@@ -652,6 +687,8 @@ int default_tile(const mpx_conv_desc& d) {
 
 // one launch of layer L's conv with the given kernel variant
 int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hipStream_t st) {
+    if (tile == 12)
+        return patchp_fits<PatchTile0>(L.d) ? launch_conv_patchp<PatchTile0>(h, p, L.d, st) : launch_conv_patchp<PatchTile2>(h, p, L.d, st);
     if (tile == 6) {
         if (L.d.cout <= 64) return launch_conv_patch<PatchTile1>(h, p, L.d, st);
         return patch_fits<PatchTile0>(L.d) ? launch_conv_patch<PatchTile0>(h, p, L.d, st) : launch_conv_patch<PatchTile2>(h, p, L.d, st);
@@ -1129,6 +1166,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv3x3p_f16x3_kernel<PatchTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3pp_f16x3_kernel<PatchTile0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv3x3pp_f16x3_kernel<PatchTile2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return (int)e; }
     *out = h;
     return 0;
@@ -1204,8 +1245,8 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10
-    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10;
+    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12
+    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12;
 #ifdef MPX_EXPERIMENTAL
     known = known || tile == 3 || tile == 5 || tile == 8 || tile == 11;
     if (tile == 11 && !convs_eligible(L))
@@ -1213,7 +1254,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
 #endif
-    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10)", tile);
+    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10, 12)", tile);
+    if (tile == 12 && !patchp_eligible(L.d))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent patch kernel (12) needs a 3x3 stride-1 layer with cout >= 128 and no residual operand whose input patch fits the LDS (%s is not one)", L.d.name);
     if (tile == 10 && !convx_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent expanding-1x1 kernel (10) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0, cin >= 128 (%s is not one)", L.d.name);
     if (tile == 9 && !conv256_eligible(L))

@@ -206,10 +206,10 @@ def test_conv_tile_ids_are_the_default_kernels(eng101):
     """The documented tile ids are exactly what default_tile hands out; the ids of kernels that never became a default (3, 5, 8, 11:
     probe builds only) and anything else are refused."""
     i = _layer_index(eng101, "layer3.5.conv3")
-    for tile in (3, 5, 8, 11, 12):
+    for tile in (3, 5, 8, 11, 13):
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, tile) == -1
     assert b"product ids" in eng101._lib.mpx_last_error(eng101._h)
-    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10}
+    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12}
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
@@ -516,6 +516,43 @@ def test_conv_patch_kernel(eng101, name, batch):
     if batch > eng101.max_batch:
         pytest.skip("engine too small")
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=6)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 11, 41, 347])
+@pytest.mark.parametrize("name", ["layer2.1.conv2", "layer3.5.conv2", "layer3.22.conv2", "layer4.1.conv2"])
+def test_conv_persistent_patch_kernel(eng101, name, batch):
+    """Tile id 12 = the patch kernel as one persistent workgroup per CU (csrc/mpx_conv3pp.h): weight ring and patch buffers run on
+    across the tiles of a workgroup, register epilogue, the next tile's geometry computed inside the K loop with float-reciprocal
+    divisions.  Batches from fewer tiles than a grid unit (that launch falls back to tile 6) over one tile per workgroup (41
+    images = 64 tiles on 14x14) to two and three per workgroup (347 images = 532 tiles on 256 CUs: tile boundaries, ragged last
+    tile, workgroups with different tile counts).  Against the fp64 conv + BN for the small batches, and BIT-identical to tile 6
+    for all of them (mpx_conv_bn_act takes any batch: the planes are the caller's)."""
+    sd = synth.make_state_dict("resnet101")
+    if batch <= 11:
+        _check_layer(eng101, sd, name, batch=batch, tile=12)
+    i = _layer_index(eng101, name)
+    d = eng101.layers[i]
+    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(7)).clamp_min(-0.5)
+    outs = []
+    for tile in (6, 12):
+        eng101.set_conv_tile(i, tile)
+        try:
+            outs.append(_run_conv(eng101, i, x, None, batch)[0])
+        finally:
+            eng101.set_conv_tile(i, -1)
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_conv_persistent_patch_kernel_eligibility(eng101, eng18):
+    for name in ("layer1.0.conv2", "layer1.0.conv1", "layer2.0.conv2", "conv1"):       # cout 64, 1x1, stride 2, stem
+        i = _layer_index(eng101, name)
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 12) == -1
+    i = _layer_index(eng18, "layer3.1.conv2")          # BasicBlock conv2: residual operand
+    assert eng18._lib.mpx_set_conv_tile(eng18._h, i, 12) == -1
+    i = _layer_index(eng18, "layer3.1.conv1")
+    eng18.set_conv_tile(i, 12)
+    eng18.set_conv_tile(i, -1)
 
 
 def test_conv_patch_kernel_eligibility(eng101):
