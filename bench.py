@@ -244,7 +244,7 @@ def main():
                         "traffic": (traffic_per_batch / (conv_n / forwards_profiled)) if traffic_per_batch else None,
                         # NOT measured in this run: PMC counters need rocprofv3; the file holds the per-batch bytes of the same forward
                         "traffic_source": traffic_source, "traffic_bytes_per_forward_batch": traffic_per_batch,
-                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel (all conv launches)", "launches": conv_n,
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv3x3pp_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)

@@ -25,14 +25,14 @@ import __graft_entry__ as g  # noqa: E402
 
 g.build()
 from network_interpretation_imagenet_amd import api, synth  # noqa: E402
-from network_interpretation_imagenet_amd.engine import MEAN, STD, MaskedForwardEngine  # noqa: E402
+from network_interpretation_imagenet_amd.engine import MEAN, STD, MaskedForwardEngine, whole_round_batch  # noqa: E402
 
 arch = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
 n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 imgs = synth.make_images(n_img, seed=99, kind="noise")
 mean, std = torch.tensor(MEAN).view(3, 1, 1), torch.tensor(STD).view(3, 1, 1)
 xs = [(torch.from_numpy(im).permute(2, 0, 1).float().div(255) - mean) / std for im in imgs]
-model = MaskedForwardEngine(arch, max_batch=2048).load_state_dict(synth.make_state_dict(arch))
+model = MaskedForwardEngine(arch, max_batch=whole_round_batch(2400)).load_state_dict(synth.make_state_dict(arch))   # 2340: whole rounds of tiles
 labels = [model.predict(x)[0] for x in xs]
 labels[1] = (labels[1] + 1) % 1000                    # one image whose unmasked prediction is "wrong": the reference skips it
 val_loader = [(x[None], torch.tensor([l])) for x, l in zip(xs, labels)]

@@ -36,8 +36,11 @@ def whole_round_batch(limit):
     whole number of rounds pays a whole extra round on the stage that holds 2/3 of an ImageNet ResNet's time: measured on
     ResNet-101 (tools/batch_sweep.sh, profiles/r03_batch_sweep.txt) 44.8 us of conv time per masked image at 2006 / 2340 /
     2674 / 3009 against 45.6-45.9 at 2010 and 2048.  Returns `limit` itself below one round."""
-    rounds = int(limit) * 196 // (COMPUTE_UNITS * ROUND_PIXELS_14)
-    return (rounds * COMPUTE_UNITS * ROUND_PIXELS_14) // 196 if rounds >= 1 else int(limit)
+    per_round = COMPUTE_UNITS * ROUND_PIXELS_14
+    rounds = int(limit) * 196 // per_round
+    if (rounds + 1) * per_round // 196 <= int(limit):       # the last tile of a batch may be partial: 2340 images are 1791.6 -> 1792 tiles
+        rounds += 1
+    return rounds * per_round // 196 if rounds >= 1 else int(limit)
 
 
 class BasePredictionWrong(Exception):

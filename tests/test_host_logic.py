@@ -503,3 +503,28 @@ def test_jet_lut_bytes_are_pinned():
     got = {i: tuple(int(v) for v in bgr[i]) for i in want}
     assert got == want, got
     assert (np.diff(bgr[:, 2].astype(int))[:223] >= 0).all() and (np.diff(bgr[:, 0].astype(int))[32:] <= 0).all()      # R rises, B falls
+
+
+def test_whole_round_batch():
+    """engine.whole_round_batch: the largest forward batch whose 14x14 maps cut into WHOLE rounds of 256-pixel tiles over 256 CUs
+    (the one-workgroup-per-CU kernels pay a full extra round for a batch just above one)."""
+    from network_interpretation_imagenet_amd.engine import whole_round_batch
+    assert whole_round_batch(2048) == 2006 and whole_round_batch(2400) == 2340 and whole_round_batch(2340) == 2340
+    assert whole_round_batch(334) == 334 and whole_round_batch(335) == 334 and whole_round_batch(100) == 100 and whole_round_batch(1) == 1
+    for limit in range(335, 5000, 37):
+        b = whole_round_batch(limit)
+        tiles = -(-b * 196 // 256)                       # 256-pixel tiles of the batch's 14x14 maps
+        assert b <= limit and tiles % 256 == 0           # whole rounds ...
+        assert -(-(b + 1) * 196 // 256) > tiles or whole_round_batch(limit) == b      # ... and one more image would start a new tile
+        nxt = (tiles // 256 + 1) * 256 * 256 // 196
+        assert nxt > limit                               # the next whole-round batch does not fit the limit
+
+
+def test_bench_traffic_lookup_prefers_the_benched_batch():
+    """bench.pmc_traffic: the PMC file of the arch taken at the benched forward batch wins; another batch is scaled and says so."""
+    import bench
+    total, src = bench.pmc_traffic("resnet101", 2048)
+    assert total and src.endswith(".json") and "scaled" not in src
+    t2, src2 = bench.pmc_traffic("resnet101", 1024)
+    assert "scaled by 1024/" in src2 and t2 < total
+    assert bench.pmc_traffic("no_such_arch", 2048) == (None, None)

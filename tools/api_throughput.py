@@ -22,7 +22,7 @@ from oracle import scorer  # noqa: E402
 
 arch = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
 n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2340      # engine.whole_round_batch(2400)
 kind = sys.argv[4] if len(sys.argv) > 4 else "noise"
 eng = MaskedForwardEngine(arch, max_batch=max_batch, device=0).load_state_dict(synth.make_state_dict(arch))
 imgs = synth.make_images(n_img, seed=5, kind=kind)

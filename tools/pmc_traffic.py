@@ -30,7 +30,7 @@ fetch = f * 1024 / nb
 write = w * 1024 / nb
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) --kernel-trace -- python3 tools/layer_profile.py "
-              "%s %d; every kernel whose name contains _f16x3_kernel = all conv launches (conv_f16x3_kernel, conv3x3p_f16x3_kernel, "
+              "%s %d; every kernel whose name contains _f16x3_kernel = all conv launches (conv_f16x3_kernel, conv3x3p_f16x3_kernel, conv3x3pp_f16x3_kernel, "
               "conv256_f16x3_kernel, convx_f16x3_kernel, btail_f16x3_kernel), per forward batch of %d masked images" % (arch, batch, batch),
     "arch": arch,
     "forward_batch": batch,
