@@ -101,6 +101,8 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
  *   9 = 256x256 tile, two 64-KB stages (reducing 1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0);
  *  10 = persistent pipelined 256x128 kernel, three stages running on across tiles (expanding 1x1 stride-1 layers with
  *       cout % 256 == 0, cin >= 128, on 28x28 / 14x14 maps);
+ *  13 = the 256x256 kernel (9) as ONE persistent workgroup per CU: the two-stage ring runs on across tiles, register epilogue (layers
+ *       eligible for 9 without a residual operand: their default; bit-identical to 9);
  *  12 = the patch kernel (6) as ONE persistent workgroup per CU: weight ring and patch buffers run on across tiles, register
  *       epilogue (layers eligible for 6 with cout >= 128 and no residual operand; the default on 28x28 / 14x14 maps; bit-identical to 6).
  * A tile a layer is not eligible for, or any other id, returns MPX_E_ARG; tile < 0 = the layer's default.  (Ids 3, 5, 8 and 11 of

@@ -5,6 +5,7 @@
 #include "mpx_conv3p.h"
 #include "mpx_conv3pp.h"
 #include "mpx_conv256.h"
+#include "mpx_conv256p.h"
 #include "mpx_convx.h"
 #include "mpx_btail.h"
 #ifdef MPX_EXPERIMENTAL
@@ -587,6 +588,26 @@ int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     return 0;
 }
 
+// persistent 256x256 kernel (mpx_conv256p.h, tile id 13): tile 9's layers without a residual operand; a launch with fewer tiles than
+// one grid unit (8 or n_tiles_c workgroups) runs on the 256x256 kernel itself (same bits)
+bool conv256p_eligible(const ConvLayer& L) { return conv256_eligible(L) && !L.d.residual; }
+
+int launch_conv256p(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    p.n_tiles_c = p.cout / Conv256P::TC;
+    if (p.n_tiles_c * Conv256P::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const long long n_tiles_p = ((long long)p.M + Conv256P::TP - 1) / Conv256P::TP;
+    const long long total = n_tiles_p * p.n_tiles_c;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    long long grid = h->num_cus;
+    if (total < grid) grid = total;
+    const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
+    grid = grid / unit * unit;
+    if (grid <= 0 || p.r_hi) return launch_conv256(h, p, cout_pad, st);
+    hipLaunchKernelGGL(conv256p_f16x3_kernel, dim3((unsigned)grid), dim3(Conv256P::NT), Conv256P::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 // Rows of the largest input patch any TP-pixel tile of an HxH map needs (mpx_conv3p.h), rounded up to 16.
 int patch_rows_needed(int H, int TP) {
     const int W = H, PW = W + 2, PIMG = (H + 2) * PW, howo = H * W;
@@ -668,7 +689,9 @@ int default_tile(const mpx_conv_desc& d) {
     if (d.cout <= 64) return d.ksize >= 3 ? 1 : 4;       // (the patch kernel is 10 % slower than tile 1 on 64->64 in the network)
     // ... as one persistent workgroup per CU (mpx_conv3pp.h) where the layer has no residual operand: in the network (batch 2340,
     // A/B in one call) 128->128 on 28x28 3.89 -> 3.67 ms, 256->256 on 14x14 24.65 -> 24.49 ms per batch; 7x7 maps lose 1 % (2.29 -> 2.32)
+#ifndef MPX_PROBE_NO_PERSISTENT_PATCH   // A/B builds only (tools/ab_lib.sh)
     if (patchp_eligible(d) && d.hout >= 14) return 12;
+#endif
     if (patch_eligible(d)) return 6;                      // 3x3 stride 1 on 28x28 / 14x14 / 7x7 maps: -10..18 % against tile 0
     if (d.ksize == 3) return 0;
     // expanding 1x1 layers (short K, long epilogue): four waves per SIMD cover the epilogue better, -2..4 % in the
@@ -681,7 +704,13 @@ int default_tile(const mpx_conv_desc& d) {
     // reducing / square 1x1 stride-1 layers with cout % 256 == 0: the 256x256 tile (mpx_conv256.h) halves the operand bytes
     // per MAC and runs +10..18 % (1024->256: 365 vs 322 TFLOP/s, 1024->512: 411 vs 346); expanding layers lose on it (one
     // workgroup per CU: nothing covers the long epilogue)
+    // ... as one persistent workgroup per CU with a register epilogue (mpx_conv256p.h) where the layer has no residual operand (all of
+    // them in the torchvision ResNets): in the network at batch 2340, A/B in one call, 1024->256 13.73 -> 13.12 ms, 512->256 1.47 -> 1.32,
+    // 1024->512 1.18 -> 1.11, 2048->512 1.11 -> 1.10 per batch
+#ifdef MPX_PROBE_NO_PERSISTENT_256      // A/B builds only (tools/ab_lib.sh)
     if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout % 256 == 0 && d.cin % 64 == 0) return 9;
+#endif
+    if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout % 256 == 0 && d.cin % 64 == 0) return d.residual ? 9 : 13;
     return 2;
 }
 
@@ -696,6 +725,7 @@ int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hi
     switch (tile) {
         case 10: return launch_convx(h, p, L.d.cout_pad, st);
         case 9: return launch_conv256(h, p, L.d.cout_pad, st);
+        case 13: return launch_conv256p(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
         case 1: return launch_conv_tile<ConvTile1>(h, p, L.d.cout_pad, st);
         case 2: return launch_conv_tile<ConvTile2>(h, p, L.d.cout_pad, st);
@@ -749,7 +779,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     // split of the 3x3 patch kernel's and tile 0's last round was measured and gains nothing: their remainder lives as long
     // as one of their tiles whatever its tile size)
     int big_tc = 0, big_tp = 0;
-    if (L.tile == 9) { big_tc = Conv256::TC; big_tp = Conv256::TP; }
+    if (L.tile == 9 || L.tile == 13) { big_tc = Conv256::TC; big_tp = Conv256::TP; }
     if (big_tc && !L.is_stem) {
         const long long tiles_c = (p.cout + big_tc - 1) / big_tc, tiles_p = (M + big_tp - 1) / big_tp;
         const long long total = tiles_p * tiles_c, rounds = total / h->num_cus, rest = total - rounds * h->num_cus;
@@ -1139,6 +1169,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv256p_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256P::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
 #ifdef MPX_EXPERIMENTAL
     if (e == hipSuccess)
@@ -1245,8 +1277,8 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12
-    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12;
+    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13
+    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12 || tile == 13;
 #ifdef MPX_EXPERIMENTAL
     known = known || tile == 3 || tile == 5 || tile == 8 || tile == 11;
     if (tile == 11 && !convs_eligible(L))
@@ -1254,7 +1286,9 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
 #endif
-    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10, 12)", tile);
+    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13)", tile);
+    if (tile == 13 && !conv256p_eligible(L))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the persistent 256x256 kernel (13) runs 1x1 stride-1 layers with cout %% 256 == 0, cin %% 64 == 0 and no residual operand (%s is not one)", L.d.name);
     if (tile == 12 && !patchp_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent patch kernel (12) needs a 3x3 stride-1 layer with cout >= 128 and no residual operand whose input patch fits the LDS (%s is not one)", L.d.name);
     if (tile == 10 && !convx_eligible(L))

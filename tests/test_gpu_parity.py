@@ -206,10 +206,10 @@ def test_conv_tile_ids_are_the_default_kernels(eng101):
     """The documented tile ids are exactly what default_tile hands out; the ids of kernels that never became a default (3, 5, 8, 11:
     probe builds only) and anything else are refused."""
     i = _layer_index(eng101, "layer3.5.conv3")
-    for tile in (3, 5, 8, 11, 13):
+    for tile in (3, 5, 8, 11, 14):
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, tile) == -1
     assert b"product ids" in eng101._lib.mpx_last_error(eng101._h)
-    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12}
+    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12, 13}
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
@@ -535,6 +535,34 @@ def test_conv_persistent_patch_kernel(eng101, name, batch):
     x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(7)).clamp_min(-0.5)
     outs = []
     for tile in (6, 12):
+        eng101.set_conv_tile(i, tile)
+        try:
+            outs.append(_run_conv(eng101, i, x, None, batch)[0])
+        finally:
+            eng101.set_conv_tile(i, -1)
+    assert not torch.isnan(outs[1]).any()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("batch", [1, 11, 41, 347, 700])
+@pytest.mark.parametrize("name", ["layer2.1.conv1", "layer3.5.conv1", "layer4.1.conv1"])
+def test_conv_persistent_256_kernel(eng101, name, batch):
+    """Tile id 13 = the 256x256 kernel as one persistent workgroup per CU (csrc/mpx_conv256p.h): the two-stage ring runs on across
+    the tiles of a workgroup (pixel descriptor switched when the fill wraps), register epilogue whose stores retire under the next
+    tile's first step (vmcnt(32) at its rendezvous).  512 -> 128 is not eligible (cout % 256); 1024 -> 256 on 14x14 and 2048 -> 512
+    on 7x7 (two cout tiles) from fewer tiles than a grid unit (that launch falls back to tile 9) to two and three tiles per
+    workgroup (347 images: 266 tiles; 700: 536).  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
+    sd = synth.make_state_dict("resnet101")
+    i = _layer_index(eng101, name)
+    d = eng101.layers[i]
+    if d.cout % 256:
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 13) == -1
+        return
+    if batch <= 11:
+        _check_layer(eng101, sd, name, batch=batch, tile=13)
+    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(11)).clamp_min(-0.5)
+    outs = []
+    for tile in (9, 13):
         eng101.set_conv_tile(i, tile)
         try:
             outs.append(_run_conv(eng101, i, x, None, batch)[0])
