@@ -554,7 +554,11 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (total < grid) grid = total;
     const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
     grid = grid / unit * unit;
-    if (grid <= 0) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);      // fewer tiles than one grid unit: the 128x128 kernel
+    // less than one round of tiles (small batches: one image's window table, a BO round): the persistent walk would serialise the
+    // tiles that do not fill a grid unit, and half-empty CUs gain more from tiles a quarter of the size -- the 128x128 kernel, which
+    // sums in the same order (bit-identical).  tools/layer_profile.py, conv ms per forward: batch 29 8.24 -> 3.92, 118 10.28 -> 6.78,
+    // 211 13.50 -> 11.62 with this rule on the three persistent kernels
+    if (grid <= 0 || total < h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
     hipLaunchKernelGGL(convx_f16x3_kernel, dim3((unsigned)grid), dim3(ConvX::NT), ConvX::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
@@ -602,7 +606,8 @@ int launch_conv256p(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) 
     if (total < grid) grid = total;
     const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
     grid = grid / unit * unit;
-    if (grid <= 0 || p.r_hi) return launch_conv256(h, p, cout_pad, st);
+    if (p.r_hi) return launch_conv256(h, p, cout_pad, st);
+    if (grid <= 0 || total < h->num_cus) return launch_conv_tile<ConvTile2>(h, p, cout_pad, st);      // under one round: smaller tiles (launch_convx)
     hipLaunchKernelGGL(conv256p_f16x3_kernel, dim3((unsigned)grid), dim3(Conv256P::NT), Conv256P::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;
@@ -673,7 +678,7 @@ int launch_conv_patchp(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hip
     grid = grid / unit * unit;
     // (the kernel divides pixel and padded-pixel indices with a float reciprocal: exact below 2^23)
     const long long padded = (long long)(p.M / (d.hin * d.hin) + 2) * (d.hin + 2) * (d.hin + 2);
-    if (grid <= 0 || p.r_hi || padded >= (1 << 23)) return launch_conv_patch<PC>(h, p, d, st);
+    if (grid <= 0 || total < h->num_cus || p.r_hi || padded >= (1 << 23)) return launch_conv_patch<PC>(h, p, d, st);     // under one round: a workgroup per tile
     hipLaunchKernelGGL(conv3x3pp_f16x3_kernel<PC>, dim3((unsigned)grid), dim3(PC::NT), lds, st, p);
     MPX_HIP(h, hipGetLastError());
     return 0;

@@ -66,6 +66,18 @@ def rank_segments(segments):
         raise ValueError("segments must be [%d,%d], got %s" % (IMG, IMG, seg.shape))
     if not np.issubdtype(seg.dtype, np.integer):
         raise ValueError("segments must be an integer label map, got %s" % seg.dtype)
+    # ranks in ascending label order = np.unique's order.  Label maps are small non-negative integers (felzenszwalb, grids, an already
+    # ranked map): a histogram ranks them in one pass -- np.unique sorts 50,176 values (1 ms, twice per score_masks call, next to
+    # ~7 ms of GPU time for a BO round's window table)
+    flat = seg.reshape(-1)
+    lo, hi = int(flat.min()), int(flat.max())
+    if lo >= 0 and hi < 4 * flat.size:
+        present = np.bincount(flat, minlength=hi + 1) > 0
+        s = int(present.sum())
+        if s == hi + 1:                                     # already 0 .. S-1 with no gap
+            return np.ascontiguousarray(seg, dtype=np.int32), s
+        rank = (np.cumsum(present) - 1).astype(np.int32)
+        return rank[flat].reshape(IMG, IMG), s
     uniq, inv = np.unique(seg, return_inverse=True)
     return inv.reshape(IMG, IMG).astype(np.int32), int(len(uniq))
 

@@ -186,6 +186,19 @@ def test_rank_segments():
         rank_segments(np.zeros((10, 10), dtype=np.int32))
     with pytest.raises(ValueError):
         rank_segments(np.zeros((224, 224), dtype=np.float32))
+    # the histogram path (small non-negative labels), the already-ranked path and the np.unique fallback (negative / huge labels)
+    # all give np.unique's ranks (generate_gp_training_data_imagenet.py:223,230 index superpixels through np.unique(segments))
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        k = int(rng.integers(1, 400))
+        pool = np.arange(-5, 900) if trial % 4 == 0 else (np.arange(0, 10**9, 997) if trial % 4 == 1 else np.arange(0, 5000))
+        labels = rng.choice(pool, size=k, replace=False)
+        seg = labels[rng.integers(0, k, size=(224, 224))].astype(np.int64 if trial % 2 else np.int32)
+        rank, s = rank_segments(seg)
+        uniq, inv = np.unique(seg, return_inverse=True)
+        assert s == len(uniq) and rank.dtype == np.int32 and rank.flags.c_contiguous and np.array_equal(rank, inv.reshape(224, 224))
+        again, s2 = rank_segments(rank)
+        assert s2 == s and np.array_equal(again, rank)
 
 
 def test_masks_module():
