@@ -12,7 +12,7 @@ bench() { cp /tmp/libmpx_$1.so network_interpretation_imagenet_amd/libmpx.so; cp
           python bench.py --steps 2 --warmup 1 --cpu-masks 0 > gpurun_out/abb_$1_$2.json 2> /dev/null
           python -c "import json,sys; j=json.load(open('gpurun_out/abb_$1_$2.json')); print('== build $1 (run $2): %.0f fwd/s, conv %.2f ms per batch of %d' % (j['value'], j['roofline']['conv_ms_per_batch'], j['config']['forward_batch']))"; }
 run() { cp /tmp/libmpx_$1.so network_interpretation_imagenet_amd/libmpx.so; cp /tmp/libmpx_A.sha256 network_interpretation_imagenet_amd/libmpx.so.sha256
-        python tools/layer_profile.py $ARCH $B $REPS > gpurun_out/ab_$1_$2.txt 2>&1; echo "== build $1 (run $2)"; grep -E "k3 s1 out14|256->1024|1024->256|conv total" gpurun_out/ab_$1_$2.txt | cut -c1-90; }
+        python tools/layer_profile.py $ARCH $B $REPS > gpurun_out/ab_$1_$2.txt 2>&1; echo "== build $1 (run $2)"; grep -E "k3 s1 out14|256->1024|1024->256|128->512|conv total" gpurun_out/ab_$1_$2.txt | cut -c1-90; }
 mkdir -p gpurun_out
 if [ -n "$AB_BENCH" ]; then bench A 1; bench B 1; bench A 2; bench B 2; else run A 1; run B 1; run A 2; run B 2; fi
 cp /tmp/libmpx_A.so network_interpretation_imagenet_amd/libmpx.so
