@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: this process starts the N ranks itself and touches no GPU)
 
 One "step" = one pass of the hot path over the workload of BASELINE configs[2]
 ("ResNet-101, 512 masks/image x 128 images, 1 MI355X"): per image, K0 stages its 512 masked
@@ -15,6 +16,8 @@ resident in HBM before the timed region.  Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +31,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA, /opt/skills/guide
 F16X3_CEILING_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three MFMA products per algorithmic product
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -45,7 +48,11 @@ def parse():
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
-    return ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true",
+                    help="TEST HOOK, not a measurement: no GPU and no engine -- gloo on the CPU and a step that fills the rank's block of "
+                         "scores with a function of the flat (image, mask) index; exercises the launcher, the rendezvous, the barrier / "
+                         "max-over-ranks timing and the all-gather, and prints a line whose `data` says \"stub\" (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
 
 
 def pmc_traffic(arch, batch):
@@ -83,49 +90,185 @@ def _cpu_model():
     return "unknown"
 
 
-def _cpu_loop(arch, n_masks, threads, seg_block=16):
-    """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per superpixel) -> (fwd/s, s)."""
+def _cpu_inputs(n_masks, seg_block=16):
+    from network_interpretation_imagenet_amd import synth
+    img = synth.make_images(1, kind="noise")[0]
+    seg = synth.grid_segments(block=seg_block)
+    return img, seg, synth.random_onoff(n_masks, int(seg.max()) + 1)
+
+
+def _cpu_loop(arch, n_masks, threads, label=0):
+    """Reference-style loop (oracle/scorer.py: batch-1 fp32 forward per mask, mask built per superpixel)
+    -> (fwd/s, s, score f32[n_masks], pred i32[n_masks])."""
     from network_interpretation_imagenet_amd import synth
     from oracle import scorer
     torch.set_num_threads(threads)
     sd = synth.make_state_dict(arch)
-    img = synth.make_images(1, kind="noise")[0]
+    img, seg, onoff = _cpu_inputs(n_masks)
     x = scorer.to_tensor_normalize(img)
-    seg = synth.grid_segments(block=seg_block)
-    onoff = synth.random_onoff(n_masks, int(seg.max()) + 1)
-    scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[:1], 0)    # warm the thread pool
+    scorer.score_masks_reference_loop(sd, arch, x, seg, onoff[:1], label)    # warm the thread pool
     t0 = time.perf_counter()
-    scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, 0)
+    score, pred = scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, label)
     dt = time.perf_counter() - t0
-    return n_masks / dt, dt
+    return n_masks / dt, dt, score, pred
 
 
-def cpu_baseline(arch, n_masks):
+def cpu_baseline(arch, n_masks, eng=None):
     """the reference-style CPU loop on this box's host cores, bounded samples: the benched arch
     (`value`, comparable with the GPU line) on all threads, and BASELINE cfg-1 exactly (ResNet-18, 1 image, 64 masks)
-    on all threads and on ONE thread; CPU model and thread count stated."""
+    on all threads and on ONE thread; CPU model and thread count stated.  With `eng` (the benched engine, same arch and the
+    same synthetic weights) the SAME masks are scored on the GPU as well: -> (cpu_baseline object, parity object) where parity
+    is the second half of BASELINE.json's metric ("score max|d| vs ref"): max |score_gpu - score_cpu| over the sample and
+    whether every argmax agrees (generate_gp_training_data_imagenet.py:246-248, bayesian_active_learning_imagenet.py:196-198)."""
+    import numpy as np
     all_threads = torch.get_num_threads()
-    v, dt = _cpu_loop(arch, n_masks, all_threads)
-    c1_all, dt_all = _cpu_loop("resnet18", 64, all_threads)
-    c1_one, dt_one = _cpu_loop("resnet18", 16, 1)
+    label, parity = 0, None
+    if eng is not None:
+        img, seg, onoff = _cpu_inputs(n_masks)
+        label, _p = eng.predict(img)                    # the reference scores the class the unmasked image is predicted as
+        _o, g_score, g_pred = eng.score_masks(img, seg, onoff, label)
+    v, dt, c_score, c_pred = _cpu_loop(arch, n_masks, all_threads, label)
+    if eng is not None:
+        parity = {"score_max_abs_delta": float(np.abs(g_score.astype(np.float64) - c_score.astype(np.float64)).max()),
+                  "argmax_agree": bool((g_pred == c_pred).all()), "tolerance": 1e-4,
+                  "sample": "%s, 1 noise image x %d masks (the cpu_baseline sample), label = unmasked argmax %d: engine.score_masks "
+                            "against the batch-1 fp32 torch-CPU loop (oracle/scorer.py)" % (arch, n_masks, label),
+                  "score_range": [float(c_score.min()), float(c_score.max())]}
+    c1_all, dt_all, _s, _p = _cpu_loop("resnet18", 64, all_threads)
+    c1_one, dt_one, _s, _p = _cpu_loop("resnet18", 16, 1)
     torch.set_num_threads(all_threads)
     from oracle import resnet_ref
     gf18 = resnet_ref.flops_per_forward("resnet18") / 1e9
-    return {"value": v, "unit": "masked-forward-passes/s", "cores": all_threads, "kind": "port",
+    base = {"value": v, "unit": "masked-forward-passes/s", "cores": all_threads, "kind": "port",
             "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s)" % (arch, n_masks, dt),
             "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(),
             "cfg1_resnet18_1x64": {"all_threads": {"value": c1_all, "threads": all_threads, "seconds": dt_all, "gflops": c1_all * gf18},
                                    "one_thread": {"value": c1_one, "threads": 1, "seconds": dt_one, "gflops": c1_one * gf18,
                                                   "sample": "16 of the 64 masks"}}}
+    return base, parity
 
 
-def main():
-    args = parse()
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), wait for them, and
+    return a non-zero code if any failed (the others are then terminated).  Rank 0's JSON line reaches stdout because the
+    children inherit it.  This parent never touches a GPU -- it builds the library (hipcc only), spawns and waits -- and
+    nothing is exec'ed from a process that has initialised one."""
+    import __graft_entry__ as g
+    g.build()                   # once, before the ranks start (they find a fresh stamp and only load it)
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = str(n)
+    env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
+def timed_steps(step, fence, steps, warmup, use_dist, device, record_events=True):
+    """The bench contract's timed region: W untimed steps, then EXACTLY K steps bracketed by fence() (barrier +
+    synchronize) on both sides, wall time MAX over ranks -> (seconds, GPU-side ms between two HIP events or None, last step's result)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    ev0 = ev1 = None
+    if record_events:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    if ev0 is not None:
+        ev0.record()
+    out = None
+    for _ in range(steps):
+        out = step()
+    if ev1 is not None:
+        ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1) if ev0 is not None else None
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, gpu_ms, out
+
+
+def stub_main(args, rank, world):
+    """--stub-step (test hook): the launcher / rendezvous / timing / all-gather skeleton of main() on the CPU under gloo."""
+    from network_interpretation_imagenet_amd import shard
+    if os.environ.get("MPX_BENCH_STUB_FAIL_RANK") == str(rank):      # the launcher test's failing rank: the others must not outlive it
+        raise SystemExit(3)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_img, n_mask = args.images, args.masks
+    total = world * n_img * n_mask
+    lo, hi = shard.block(total, rank, world)
+    w = torch.arange(lo, hi, dtype=torch.float64)
+
+    def step():
+        local = (torch.sin(w * 0.37) * 0.5 + 0.5).to(torch.float32)
+        return shard.all_gather_blocks(local, total) if use_dist else local
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+
+    dt, _ms, out = timed_steps(step, fence, args.steps, args.warmup, use_dist, torch.device("cpu"), record_events=False)
+    want = (torch.sin(torch.arange(total, dtype=torch.float64) * 0.37) * 0.5 + 0.5).to(torch.float32)
+    assert out.numel() == total and bool((out == want).all()), "stub: gathered scores differ from the single-process values"
+    if rank == 0:
+        print(json.dumps({"metric": "masked-forward-passes/sec (stub)", "value": total * args.steps / dt, "unit": "masked-forward-passes/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "stub (TEST HOOK: no GPU, no engine, gloo on the CPU -- not a measurement)",
+                          "config": {"workload": "stub step, %d x %d indices per rank (x%d ranks)" % (n_img, n_mask, world)}}))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without a launcher: this process becomes one (it never initialises a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under torch.distributed.run with "
+                         "--nproc-per-node N)" % (args.gpus, world))
+    if args.stub_step:
+        return stub_main(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -148,7 +291,7 @@ def main():
     if args.images_per_forward:
         batch = args.images_per_forward * n_mask
     else:
-        batch = args.forward_batch or whole_round_batch(2400)
+        batch = args.forward_batch or whole_round_batch(2400, num_cus=torch.cuda.get_device_properties(local_rank).multi_processor_count)
     batch = min(batch, n_img * n_mask)
     batches_per_step = n_img * n_mask / batch          # forward batches per step (the last one of a step may be partial)
     sd = synth.make_state_dict(args.arch)
@@ -189,24 +332,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
     # the timed region: exactly K steps, nothing but the step inside (no per-kernel events, no allocation); ONE pair of
     # HIP events on the launch stream brackets it for the GPU-side time
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out = step()
-    ev1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    gpu_ms_timed = ev0.elapsed_time(ev1)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, gpu_ms_timed, out = timed_steps(step, fence, args.steps, args.warmup, use_dist, dev)
     assert out.numel() == total and bool(torch.isfinite(out).all())
     # per-kernel durations: ONE more step of the same work after the timed region, every launch bracketed by HIP events
     # on its stream (engine profile pool)
@@ -261,12 +389,19 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
-                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "entry": "MaskedForwardEngine.score_packed",
+                       "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "num_cus": eng.num_cus,
+                       "entry": "MaskedForwardEngine.score_packed",
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,
-            "cpu_baseline": cpu_baseline(args.arch, args.cpu_masks) if (world == 1 and args.cpu_masks > 0) else None,
         }
+        # CPU baseline on rank 0 at N=1 only (bounded sample) -- and the metric's second half on the same masks: the engine's
+        # scores against the reference-style CPU loop
+        base, parity = cpu_baseline(args.arch, args.cpu_masks, eng) if (world == 1 and args.cpu_masks > 0) else (None, None)
+        line["cpu_baseline"] = base
+        line["score_max_abs_delta"] = parity["score_max_abs_delta"] if parity else None
+        line["argmax_agree"] = parity["argmax_agree"] if parity else None
+        line["parity"] = parity
         print(json.dumps(line))
     eng.close()
     if use_dist:

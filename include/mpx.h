@@ -69,6 +69,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out);
 int mpx_destroy(mpx_engine* h);
 const char* mpx_last_error(const mpx_engine* h);   /* "" if none; valid until next call */
 int mpx_max_batch(const mpx_engine* h);
+/* Compute units of the engine's device (hipDeviceAttributeMultiprocessorCount, read by mpx_create): the persistent kernels launch
+ * one workgroup per CU, so a forward batch is best a whole number of `num_cus * 256`-pixel rounds of the 14x14 maps
+ * (engine.whole_round_batch). */
+int mpx_num_cus(const mpx_engine* h);
 /* 224/3/1000/1000 for the ImageNet ResNets, 28/1/10/16 and 32/3/10/16 for the small networks; any pointer may be NULL */
 int mpx_geometry(const mpx_engine* h, int* image_size, int* in_channels, int* num_classes, int* logit_pitch);
 size_t mpx_workspace_bytes(const mpx_engine* h);
@@ -111,6 +115,11 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
  * layer (mpx_bottleneck_tail). */
 int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
 int mpx_get_conv_tile(const mpx_engine* h, int i);
+/* Test hook: which kernels the LAST mpx_conv_bn_act call launched, as a bit mask over the tile ids above (bit t = the kernel of tile
+ * t ran).  A layer's tile is a request: a launch under one round of tiles of a persistent kernel (10, 12, 13) runs on the small-tile
+ * kernel that sums in the same order (7, 6, 2), a residual operand sends 13 to 9, and the 256x256 kernels hand the images behind the
+ * last whole round to tile 2 -- so a test that means to cover a persistent walk asserts that it ran. */
+int mpx_last_conv_kernels(const mpx_engine* h);
 
 /* Host-only packer (no GPU needed; what mpx_set_conv_weights runs before the upload).
  * Produces the fp16 planes w_hi/w_lo of cout_pad x k_packed elements (k order = (ky,kx,ci), ci fastest;

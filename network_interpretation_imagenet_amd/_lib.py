@@ -37,6 +37,7 @@ SIGNATURES = {
     "mpx_destroy": (_i, [_vp]),
     "mpx_last_error": (C.c_char_p, [_vp]),
     "mpx_max_batch": (_i, [_vp]),
+    "mpx_num_cus": (_i, [_vp]),
     "mpx_workspace_bytes": (C.c_size_t, [_vp]),
     "mpx_num_convs": (_i, [_vp]),
     "mpx_conv_info": (_i, [_vp, _i, C.POINTER(ConvDesc)]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "mpx_weights_complete": (_i, [_vp]),
     "mpx_set_conv_tile": (_i, [_vp, _i, _i]),
     "mpx_get_conv_tile": (_i, [_vp, _i]),
+    "mpx_last_conv_kernels": (_i, [_vp]),
     "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

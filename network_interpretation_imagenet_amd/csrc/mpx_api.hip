@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace mpx;
@@ -123,6 +124,7 @@ struct mpx_engine {
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
     std::string err;
     bool in_forward = false;
+    unsigned last_kernels = 0;      // bit t: the last conv call launched the kernel of tile id t (mpx_last_conv_kernels)
     bool fuse_ds = true;    // mpx_forward runs a block's last conv and its downsample conv as one launch (mpx_set_fusion)
     bool fuse_pool = true;  // ... and the ImageNet stem conv with its 3x3 stride-2 max pool (mpx_stem_conv_maxpool)
     bool prof_on = false;
@@ -496,6 +498,13 @@ struct ProfScope {
     }
 };
 
+// tile id (mpx_set_conv_tile) of a shape of the generic kernel
+template <class Cfg>
+constexpr int tile_id_of() {
+    return std::is_same<Cfg, ConvTile0>::value ? 0 : std::is_same<Cfg, ConvTile1>::value ? 1 : std::is_same<Cfg, ConvTile2>::value ? 2 :
+           std::is_same<Cfg, ConvTile4>::value ? 4 : std::is_same<Cfg, ConvTile7>::value ? 7 : 31;       // 31: a probe build's shape
+}
+
 template <class Cfg, bool DUAL = false>
 int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     p.n_tiles_c = (p.cout + Cfg::TC - 1) / Cfg::TC;     // weights are padded to cout_pad >= n_tiles_c * TC rows
@@ -507,6 +516,7 @@ int launch_conv_tile(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st)
         return fail(h, MPX_E_INTERNAL, "dual conv: k1/32 - ring depth must be even and >= 0");
     hipLaunchKernelGGL((conv_f16x3_kernel<Cfg, DUAL>), dim3((unsigned)nblocks), dim3(Cfg::NT), Cfg::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << tile_id_of<Cfg>();
     return 0;
 }
 
@@ -561,6 +571,7 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (grid <= 0 || total < h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
     hipLaunchKernelGGL(convx_f16x3_kernel, dim3((unsigned)grid), dim3(ConvX::NT), ConvX::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 10;
     return 0;
 }
 
@@ -589,6 +600,7 @@ int launch_conv256(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
     hipLaunchKernelGGL(conv256_f16x3_kernel, dim3((unsigned)nblocks), dim3(Conv256::NT), Conv256::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 9;
     return 0;
 }
 
@@ -610,6 +622,7 @@ int launch_conv256p(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) 
     if (grid <= 0 || total < h->num_cus) return launch_conv_tile<ConvTile2>(h, p, cout_pad, st);      // under one round: smaller tiles (launch_convx)
     hipLaunchKernelGGL(conv256p_f16x3_kernel, dim3((unsigned)grid), dim3(Conv256P::NT), Conv256P::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 13;
     return 0;
 }
 
@@ -650,6 +663,7 @@ int launch_conv_patch(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hipS
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
     hipLaunchKernelGGL(conv3x3p_f16x3_kernel<PC>, dim3((unsigned)nblocks), dim3(PC::NT), lds, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 6;
     return 0;
 }
 
@@ -681,6 +695,7 @@ int launch_conv_patchp(mpx_engine* h, ConvParams& p, const mpx_conv_desc& d, hip
     if (grid <= 0 || total < h->num_cus || p.r_hi || padded >= (1 << 23)) return launch_conv_patch<PC>(h, p, d, st);     // under one round: a workgroup per tile
     hipLaunchKernelGGL(conv3x3pp_f16x3_kernel<PC>, dim3((unsigned)grid), dim3(PC::NT), lds, st, p);
     MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 12;
     return 0;
 }
 
@@ -776,6 +791,7 @@ int launch_conv(mpx_engine* h, int i, const half_t* in_hi, const half_t* in_lo, 
     p.stamps = h->stamps;
 #endif
     ProfScope ps(h, st, OP_CONV, i);
+    h->last_kernels = 0;
     // The 256x256 kernel keeps ONE workgroup per CU, so a launch runs in "rounds" of num_cus tiles and a small remainder would
     // keep most CUs idle for a whole tile time (14x14 maps at batch 2048: 1568 tiles = 6.125 rounds).  Then the images of
     // the whole rounds go to that kernel and the last few images (images are independent: an image range is a pointer
@@ -1226,6 +1242,8 @@ int mpx_destroy(mpx_engine* h) {
 
 const char* mpx_last_error(const mpx_engine* h) { return h ? h->err.c_str() : "null engine"; }
 int mpx_max_batch(const mpx_engine* h) { return h ? h->max_batch : MPX_E_ARG; }
+int mpx_num_cus(const mpx_engine* h) { return h ? h->num_cus : MPX_E_ARG; }
+int mpx_last_conv_kernels(const mpx_engine* h) { return h ? (int)h->last_kernels : MPX_E_ARG; }
 size_t mpx_workspace_bytes(const mpx_engine* h) { return h ? h->arena_bytes : 0; }
 int mpx_num_convs(const mpx_engine* h) { return h ? (int)h->convs.size() : MPX_E_ARG; }
 
@@ -1558,6 +1576,21 @@ int mpx_bottleneck_tail(mpx_engine* h, int i, const void* t1_hi, const void* t1_
     for (size_t k = 0; k < h->tails.size(); ++k)
         if (h->tails[k].c2 == i) ti = (int)k;
     if (ti < 0) return fail(h, MPX_E_ARG, "bottleneck_tail: layer %d is not the conv2 of a block whose tail runs as one launch", i);
+    {
+        // the four plane pairs must not overlap: workgroups read t1's halo and the identity while others write out / next
+        const TailBlock& tb = h->tails[ti];
+        const size_t px = (size_t)B * h->convs[tb.c2].d.hin * h->convs[tb.c2].d.hin * sizeof(half_t);
+        const size_t c_x = tb.ds >= 0 ? BT_MID : BT_OUT, c_next = (size_t)h->convs[tb.next1].d.cout;
+        struct Range { const char* lo; size_t n; const char* what; };
+        const Range r[8] = {{(const char*)t1_hi, px * BT_MID, "t1_hi"}, {(const char*)t1_lo, px * BT_MID, "t1_lo"},
+                            {(const char*)x_hi, px * c_x, "x_hi"}, {(const char*)x_lo, px * c_x, "x_lo"},
+                            {(const char*)out_hi, px * BT_OUT, "out_hi"}, {(const char*)out_lo, px * BT_OUT, "out_lo"},
+                            {(const char*)next_hi, px * c_next, "next_hi"}, {(const char*)next_lo, px * c_next, "next_lo"}};
+        for (int a = 0; a < 8; ++a)
+            for (int b = a + 1; b < 8; ++b)
+                if (r[a].lo && r[b].lo && r[a].lo < r[b].lo + r[b].n && r[b].lo < r[a].lo + r[a].n)
+                    return fail(h, MPX_E_ARG, "bottleneck_tail: planes %s and %s overlap (all plane pairs must be distinct buffers)", r[a].what, r[b].what);
+    }
     MPX_SET_DEVICE(h);
     return launch_btail(h, ti, (const half_t*)t1_hi, (const half_t*)t1_lo, (const half_t*)x_hi, (const half_t*)x_lo, (half_t*)out_hi,
                         (half_t*)out_lo, (half_t*)next_hi, (half_t*)next_lo, B, as_stream(stream));

@@ -26,17 +26,27 @@ ARCH_IDS = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "resnet101": 101, "r
             "mnist_net": 1, "cifar_resnet20": 2020, "cifar_resnet56": 2056, "cifar_resnet110": 2110}
 
 
-COMPUTE_UNITS = 256        # MI355X
+COMPUTE_UNITS = 256        # MI355X; only what whole_round_batch falls back to when no GPU is visible (CPU tests, documentation)
 ROUND_PIXELS_14 = 256      # pixels per tile of the kernels that run ONE workgroup per CU on the 14x14 maps (mpx_conv3p.h, mpx_conv256.h)
 
 
-def whole_round_batch(limit):
-    """Largest forward batch <= `limit` whose 14x14 maps cut into whole rounds of 256-pixel tiles over the 256 CUs
-    (334.37 images per round).  The 3x3 patch kernel and the 256x256 tile keep one workgroup per CU, so a batch just ABOVE a
-    whole number of rounds pays a whole extra round on the stage that holds 2/3 of an ImageNet ResNet's time: measured on
-    ResNet-101 (tools/batch_sweep.sh, profiles/r03_batch_sweep.txt) 44.8 us of conv time per masked image at 2006 / 2340 /
-    2674 / 3009 against 45.6-45.9 at 2010 and 2048.  Returns `limit` itself below one round."""
-    per_round = COMPUTE_UNITS * ROUND_PIXELS_14
+def device_compute_units(device=None):
+    """Compute units of the GPU the engine will run on -- the number mpx_create reads (hipDeviceAttributeMultiprocessorCount; the
+    engine reports it as MaskedForwardEngine.num_cus / mpx_num_cus) and the persistent kernels size their grids from.  256 on a
+    whole MI355X; a partitioned or CU-masked device reports fewer.  Falls back to 256 without a GPU."""
+    if torch.cuda.is_available():
+        return int(torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device).multi_processor_count)
+    return COMPUTE_UNITS
+
+
+def whole_round_batch(limit, num_cus=None):
+    """Largest forward batch <= `limit` whose 14x14 maps cut into whole rounds of 256-pixel tiles over the device's `num_cus`
+    compute units (None = device_compute_units(); 256 CUs: 334.37 images per round).  The 3x3 patch kernel and the 256x256 tile
+    keep one workgroup per CU, so a batch just ABOVE a whole number of rounds pays a whole extra round on the stage that holds
+    2/3 of an ImageNet ResNet's time: measured on ResNet-101 (tools/batch_sweep.sh, profiles/r03_batch_sweep.txt) 44.8 us of
+    conv time per masked image at 2006 / 2340 / 2674 / 3009 against 45.6-45.9 at 2010 and 2048.  Returns `limit` itself below
+    one round."""
+    per_round = (device_compute_units() if num_cus is None else int(num_cus)) * ROUND_PIXELS_14
     rounds = int(limit) * 196 // per_round
     if (rounds + 1) * per_round // 196 <= int(limit):       # the last tile of a batch may be partial: 2340 images are 1791.6 -> 1792 tiles
         rounds += 1
@@ -105,6 +115,7 @@ class MaskedForwardEngine:
             _lib.check(h, self._lib.mpx_conv_info(h, i, C.byref(d)), "mpx_conv_info")
             self.layers.append(d)
         self.flops_per_forward = float(self._lib.mpx_flops_per_forward(h))
+        self.num_cus = int(self._lib.mpx_num_cus(h))        # what the persistent kernels' grids are sized from (whole_round_batch)
         self._mean, self._std = _f3(MEAN), _f3(STD)
         g = [C.c_int() for _ in range(4)]
         _lib.check(h, self._lib.mpx_geometry(h, *[C.byref(v) for v in g]), "mpx_geometry")
@@ -136,10 +147,17 @@ class MaskedForwardEngine:
         return int(self._lib.mpx_workspace_bytes(self._h))
 
     # ---- weights ----
-    def load_state_dict(self, sd, eps=BN_EPS):
+    def load_state_dict(self, sd, eps=BN_EPS, only=None):
         """`sd`: torchvision ResNet state_dict (key names as `models.<arch>().state_dict()`), e.g.
-        torch.load(local_path, weights_only=True).  `module.` prefixes (DataParallel) are accepted."""
+        torch.load(local_path, weights_only=True).  `module.` prefixes (DataParallel) are accepted.  `only`: conv names
+        ("layer1.1.conv3", "fc") to (re)load instead of every layer -- the engine rebuilds whatever it derived from a reloaded
+        layer (the K-concatenated conv3 | downsample planes, a block tail's permuted copy)."""
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        if only is not None:
+            only = set(only)
+            unknown = only - {d.name.decode() for d in self.layers}
+            if unknown:
+                raise KeyError("no such conv layers: %s" % sorted(unknown))
 
         def get(key, shape):
             if key not in sd:
@@ -151,6 +169,8 @@ class MaskedForwardEngine:
 
         for i, d in enumerate(self.layers):
             name, bn = d.name.decode(), d.bn_name.decode()
+            if only is not None and name not in only:
+                continue
             wshape = (d.cout, d.cin) if (d.ksize == 1 and sd[name + ".weight"].dim() == 2) else (d.cout, d.cin, d.ksize, d.ksize)
             w = get(name + ".weight", wshape)
             if not bn:          # no BatchNorm: fc, or the MNIST net's conv6 -- the layer's own bias goes in as `beta`
@@ -447,13 +467,18 @@ class MaskedForwardEngine:
         the layout shard.heatmap_sharded closes with ONE all_reduce.  -> (score f32[M], pred i32[M]) device tensors."""
         if buf.dtype != torch.float32 or buf.device != self.device or buf.numel() != IMG * IMG + 1 or not buf.is_contiguous():
             raise ValueError("buf must be a contiguous float32[%d] tensor on %s" % (IMG * IMG + 1, self.device))
-        onoff = np.ascontiguousarray(onoff, dtype=np.uint8)
+        seg_rank, s = rank_segments(seg_rank)               # a rank map passes through on the histogram's fast path
+        onoff = np.ascontiguousarray(onoff)
+        if onoff.dtype != np.uint8 or onoff.ndim != 2 or onoff.shape[1] != s:
+            raise ValueError("onoff must be uint8[M,%d] (S = number of distinct segment labels), got %s%s" % (s, onoff.dtype, onoff.shape))
+        if not 0 <= int(label) < NUM_CLASSES:
+            raise ValueError("label %r outside [0,1000)" % (label,))
         m = int(onoff.shape[0])
         score = torch.empty(m, dtype=torch.float32, device=self.device)
         pred = torch.empty(m, dtype=torch.int32, device=self.device)
         if m == 0:
             return score, pred
-        seg_d = torch.from_numpy(np.ascontiguousarray(seg_rank, dtype=np.int32)).to(self.device)
+        seg_d = torch.from_numpy(seg_rank).to(self.device)
         onoff_d = torch.from_numpy(onoff).to(self.device)
         labels = torch.full((m,), int(label), dtype=torch.int32, device=self.device)
         self.score_packed([self._image_to_device(image)], seg_d, [onoff_d], labels, score, pred)

@@ -74,8 +74,10 @@ def score_sharded(score_image_fn, num_images, masks_per_image, device, group=Non
 def score_masks_sharded(engine, image, segments, onoff, label, group=None):
     """Single-image case (BASELINE config 5: one image, every candidate window of a BO round): shard the MASK
     axis, every rank holds the image.  Each rank scores its contiguous block of mask-vectors with its own engine
-    and one all-gather returns the full (score f32[M], pred i32[M]) on every rank -- bit-identical to one engine
-    scoring all M (same kernels, disjoint blocks)."""
+    and ONE all-gather returns the full (score f32[M], pred i32[M]) on every rank -- bit-identical to one engine
+    scoring all M (same kernels, disjoint blocks).  The scores travel as their bit patterns next to the predictions in one
+    i32[2 * width] buffer per rank ("one RCCL all_gather"); nothing is converted, so NaN payloads and signed
+    zeros arrive as they left."""
     import numpy as np
     m = int(onoff.shape[0])
     if dist.is_available() and dist.is_initialized():
@@ -84,12 +86,27 @@ def score_masks_sharded(engine, image, segments, onoff, label, group=None):
         rank, world = 0, 1
     lo, hi = block(m, rank, world)
     _o, score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    pred = np.ascontiguousarray(pred, dtype=np.int32)
+    if world == 1:
+        return score, pred
     device = getattr(engine, "device", torch.device("cpu"))
-    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
+    if dist.get_backend(group) == "gloo":
         device = torch.device("cpu")
-    s_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(score)).to(device), m, group)
-    p_all = all_gather_blocks(torch.from_numpy(np.ascontiguousarray(pred)).to(device), m, group)
-    return s_all.cpu().numpy(), p_all.cpu().numpy()
+    width = -(-m // world)
+    mine = np.zeros((2, width), dtype=np.int32)
+    mine[0, :hi - lo] = score.view(np.int32)
+    mine[1, :hi - lo] = pred
+    gathered = torch.empty(world * 2 * width, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(gathered, torch.from_numpy(mine.reshape(-1)).to(device), group=group)
+    g = gathered.cpu().numpy().reshape(world, 2, width)
+    s_all = np.empty(m, dtype=np.float32)
+    p_all = np.empty(m, dtype=np.int32)
+    for r in range(world):
+        rlo, rhi = block(m, r, world)
+        s_all[rlo:rhi] = g[r, 0, :rhi - rlo].view(np.float32)
+        p_all[rlo:rhi] = g[r, 1, :rhi - rlo]
+    return s_all, p_all
 
 
 def all_reduce_heatmap(heat, group=None):

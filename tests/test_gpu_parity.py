@@ -234,13 +234,18 @@ def test_convx_persistent_expanding_kernel(eng101, name, batch):
     """Tile id 10 = the persistent pipelined kernel for expanding 1x1 layers (csrc/mpx_convx.h): three-stage ring that runs on
     across the tiles of a workgroup, register epilogue with residual lines requested two K steps ahead, position-dependent
     counted vmcnt waits.  Batches give from one tile per workgroup (no tile boundary) up to four (boundaries, ragged last
-    tile), K = 128 (two step pairs) to 2048, with and without residual.  layer1.1.conv3 (K = 64) is not eligible; one image of
-    layer3.5.conv1 is 2 tiles, fewer than a grid unit of 8 workgroups: that launch runs on the 128x128 kernel."""
+    tile), K = 128 (two step pairs) to 2048, with and without residual.  layer1.1.conv3 (K = 64) is not eligible; a launch with
+    fewer tiles than CUs (layer3.5.conv3 at 5 images = 32 tiles, layer3.5.conv1 at 1) runs on the 128x128 8-wave kernel, which sums
+    in the same order -- the test asserts which kernel ran."""
     i = _layer_index(eng101, name)
-    if eng101.layers[i].cin < 128:
+    d = eng101.layers[i]
+    if d.cin < 128:
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 10) == -1
         return
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=10)
+    mask = eng101._lib.mpx_last_conv_kernels(eng101._h)
+    tiles = -(-batch * d.hout * d.hout // 128) * (d.cout // 256)
+    assert mask == (1 << 10 if tiles >= eng101.num_cus else 1 << 7), (mask, tiles)       # under one round of tiles: the 128x128 8-wave kernel
 
 
 def test_stress_sweep_distinct_shapes(eng101):
@@ -393,6 +398,20 @@ def test_bottleneck_tail_argument_errors(eng101, eng18, dev):
     assert lib.mpx_bottleneck_tail(h, c2, _p(t), None, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 1, None) == -1       # half a plane pair
     assert lib.mpx_bottleneck_tail(h, c2, _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 0, None) == -1
     assert b"bottleneck_tail" in lib.mpx_last_error(h)
+    # aliased planes: the layer-by-layer API lets a caller reuse a dead buffer, this launch does not (workgroups read t1's halo and
+    # the identity while others write) -- rejected, not raced
+    n = 56 * 56
+    bufs = [torch.zeros(n * c, dtype=torch.float16, device=dev) for c in (64, 64, 256, 256, 256, 256, 64, 64)]
+    ptrs = [_p(b) for b in bufs]
+    for a, b in ((4, 2), (5, 3), (6, 0), (4, 5), (7, 1)):          # out = x, out_lo = x_lo, next = t1, out_hi = out_lo, next_lo = t1_lo
+        q = list(ptrs)
+        q[a] = q[b]
+        assert lib.mpx_bottleneck_tail(h, c2, *q, 1, None) == -1 and b"overlap" in lib.mpx_last_error(h)
+    q = list(ptrs)
+    q[4] = C.c_void_p(bufs[2].data_ptr() + 256)                     # partial overlap of out_hi with x_hi
+    assert lib.mpx_bottleneck_tail(h, c2, *q, 1, None) == -1 and b"x_hi and out_hi overlap" in lib.mpx_last_error(h)
+    assert lib.mpx_bottleneck_tail(h, c2, *ptrs, 1, None) == 0     # distinct buffers: accepted
+    torch.cuda.synchronize()
     assert eng18.bottleneck_tails() == []              # basic blocks have no such tail
     assert lib.mpx_bottleneck_tail_info(h, 3, None, None, None, None) == -1
 
@@ -427,6 +446,48 @@ def test_forward_fused_vs_unfused_downsample(eng101):
         eng101.set_fusion(True)
     assert np.abs(s_fused - s_plain).max() <= 2e-6 and (p_fused == p_plain).all()
     assert not (s_fused == s_plain).all()          # they really are two code paths
+
+
+@pytest.mark.parametrize("name,unfused_mask", [("layer1.1.conv3", 1), ("layer1.0.conv3", 1), ("layer1.0.downsample.0", 0),
+                                               ("layer2.0.downsample.0", 0), ("layer3.0.conv3", 0), ("layer1.2.conv2", 1), ("layer2.0.conv1", 1)])
+def test_reloading_one_layer_rebuilds_what_was_derived_from_it(mpx_lib, dev, name, unfused_mask):
+    """mpx_set_conv_weights on ONE layer after the engine is complete (mpx_api.hip: the tail's permuted conv3 copy, the
+    K-concatenated conv3 | downsample planes and the tail copy of THOSE are derived tensors): the fused forward must follow the
+    new weights exactly as the layer-by-layer forward does -- within 2e-6 of it before and after, different from before, and
+    bit-equal to an engine that was loaded with the new state_dict from the start."""
+    arch = "resnet50"
+    sd = synth.make_state_dict(arch)
+    rng = np.random.default_rng(3)
+    sd2 = dict(sd)
+    w = sd[name + ".weight"]
+    sd2[name + ".weight"] = (w * torch.from_numpy(rng.uniform(0.5, 1.5, size=tuple(w.shape)).astype(np.float32))).contiguous()
+    img = synth.make_images(1, seed=31, kind="noise")[0]
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(12, 196, seed=32)
+    eng = MaskedForwardEngine(arch, max_batch=12, device=0).load_state_dict(sd)
+    fresh = MaskedForwardEngine(arch, max_batch=12, device=0).load_state_dict(sd2)
+    try:
+        def both():
+            _o, s_f, p_f = eng.score_masks(img, seg, onoff, 17)
+            eng.set_fusion(unfused_mask)
+            try:
+                _o, s_u, p_u = eng.score_masks(img, seg, onoff, 17)
+            finally:
+                eng.set_fusion(True)
+            assert np.abs(s_f - s_u).max() <= 2e-6 and (p_f == p_u).all()
+            return s_f, s_u
+        before_f, before_u = both()
+        eng.load_state_dict(sd2, only=[name])
+        after_f, after_u = both()
+        assert not (after_f == before_f).all() and not (after_u == before_u).all()       # the reload is visible on both paths
+        _o, want, _p2 = fresh.score_masks(img, seg, onoff, 17)
+        assert (after_f == want).all(), "fused planes were not rebuilt from the reloaded %s" % name
+        eng.load_state_dict(sd, only=[name])                                               # and back
+        _o, again, _p3 = eng.score_masks(img, seg, onoff, 17)
+        assert (again == before_f).all()
+    finally:
+        eng.close()
+        fresh.close()
 
 
 @pytest.mark.parametrize("which", ["resnet18", "resnet101"])
@@ -518,40 +579,64 @@ def test_conv_patch_kernel(eng101, name, batch):
     _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=6)
 
 
-@pytest.mark.parametrize("batch", [1, 3, 11, 41, 347])
+def _kernels_ran(eng):
+    """Tile ids of the kernels the last mpx_conv_bn_act call launched (mpx_last_conv_kernels)."""
+    mask = eng._lib.mpx_last_conv_kernels(eng._h)
+    return {t for t in range(32) if mask >> t & 1}
+
+
+def _tiles_of(eng, d, batch, tp, tc):
+    """Tiles of a launch: pixel tiles of `tp` x cout tiles of `tc`."""
+    return -(-batch * d.hout * d.hout // tp) * (d.cout // tc)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 11, 41, 335, 347, 392, 523])
 @pytest.mark.parametrize("name", ["layer2.1.conv2", "layer3.5.conv2", "layer3.22.conv2", "layer4.1.conv2"])
 def test_conv_persistent_patch_kernel(eng101, name, batch):
     """Tile id 12 = the patch kernel as one persistent workgroup per CU (csrc/mpx_conv3pp.h): weight ring and patch buffers run on
     across the tiles of a workgroup, register epilogue, the next tile's geometry computed inside the K loop with float-reciprocal
-    divisions.  Batches from fewer tiles than a grid unit (that launch falls back to tile 6) over one tile per workgroup (41
-    images = 64 tiles on 14x14) to two and three per workgroup (347 images = 532 tiles on 256 CUs: tile boundaries, ragged last
-    tile, workgroups with different tile counts).  Against the fp64 conv + BN for the small batches, and BIT-identical to tile 6
-    for all of them (mpx_conv_bn_act takes any batch: the planes are the caller's)."""
+    divisions.  A launch with fewer tiles than CUs runs on tile 6 itself (launch_conv_patchp: batches 1 .. 41 on 14x14 / 7x7 maps,
+    1 .. 11 on 28x28) -- those cases check the fallback rule; the larger batches stay on the persistent walk with UNEVEN tile counts
+    per workgroup: 256 -> 256 on 14x14 maps (two cout tiles) 335 images = 257 x 2 tiles, 347 = 266 x 2, 392 = 301 x 2, 523 = 401 x 2;
+    128 -> 128 on 28x28 maps 335 images = 1026 tiles; 512 -> 512 on 7x7 maps (192-pixel tiles, four cout tiles) 41 images = 44 and
+    335 = 344 tiles.  Every case asserts which kernel ran.  Against the fp64 conv + BN for the small batches, and
+    BIT-identical to tile 6 for all of them (mpx_conv_bn_act takes any batch: the planes are the caller's)."""
     sd = synth.make_state_dict("resnet101")
     if batch <= 11:
         _check_layer(eng101, sd, name, batch=batch, tile=12)
     i = _layer_index(eng101, name)
     d = eng101.layers[i]
+    if d.hout == 28 and batch > 347:
+        pytest.skip("28x28 maps: 347 images are 1063 tiles already")
     x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(7)).clamp_min(-0.5)
-    outs = []
+    outs, ran = [], []
     for tile in (6, 12):
         eng101.set_conv_tile(i, tile)
         try:
             outs.append(_run_conv(eng101, i, x, None, batch)[0])
+            ran.append(_kernels_ran(eng101))
         finally:
             eng101.set_conv_tile(i, -1)
+    tp, tc = (192, 128) if d.hout == 7 else (256, 128)          # PatchTile2 on 7x7 maps, PatchTile0 elsewhere
+    persistent = _tiles_of(eng101, d, batch, tp, tc) >= eng101.num_cus
+    assert ran[0] == {6} and ran[1] == ({12} if persistent else {6}), (ran, _tiles_of(eng101, d, batch, tp, tc))
+    if batch >= 335:
+        assert persistent, "this batch is meant to stay on the persistent walk"
     assert not torch.isnan(outs[1]).any()
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("batch", [1, 11, 41, 347, 700])
+@pytest.mark.parametrize("batch", [1, 11, 41, 335, 347, 392, 700, 1013])
 @pytest.mark.parametrize("name", ["layer2.1.conv1", "layer3.5.conv1", "layer4.1.conv1"])
 def test_conv_persistent_256_kernel(eng101, name, batch):
     """Tile id 13 = the 256x256 kernel as one persistent workgroup per CU (csrc/mpx_conv256p.h): the two-stage ring runs on across
     the tiles of a workgroup (pixel descriptor switched when the fill wraps), register epilogue whose stores retire under the next
-    tile's first step (vmcnt(32) at its rendezvous).  512 -> 128 is not eligible (cout % 256); 1024 -> 256 on 14x14 and 2048 -> 512
-    on 7x7 (two cout tiles) from fewer tiles than a grid unit (that launch falls back to tile 9) to two and three tiles per
-    workgroup (347 images: 266 tiles; 700: 536).  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
+    tile's first step (vmcnt(32) at its rendezvous).  512 -> 128 is not eligible (cout % 256).  A launch with fewer tiles than CUs
+    runs on the 128x128 kernel, which sums in the same order (launch_conv256p); from one round on the persistent walk runs, and when
+    a small last round is left (launch_conv: rest <= half the CUs) the images behind the whole rounds go to the 128x128 kernel too:
+    1024 -> 256 on 14x14 at 335 / 347 images = 257 / 266 tiles -> 256 persistent + the rest on tile 2; 392 images = 301 tiles and
+    700 = 536 -> all persistent, uneven tile counts per workgroup; 2048 -> 512 on 7x7 (two cout tiles) at 700 / 1013 images.  Every
+    case asserts which kernels ran.  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
     sd = synth.make_state_dict("resnet101")
     i = _layer_index(eng101, name)
     d = eng101.layers[i]
@@ -561,13 +646,22 @@ def test_conv_persistent_256_kernel(eng101, name, batch):
     if batch <= 11:
         _check_layer(eng101, sd, name, batch=batch, tile=13)
     x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(11)).clamp_min(-0.5)
-    outs = []
+    outs, ran = [], []
     for tile in (9, 13):
         eng101.set_conv_tile(i, tile)
         try:
             outs.append(_run_conv(eng101, i, x, None, batch)[0])
+            ran.append(_kernels_ran(eng101))
         finally:
             eng101.set_conv_tile(i, -1)
+    total, cus = _tiles_of(eng101, d, batch, 256, 256), eng101.num_cus
+    rest = total % cus
+    split = total >= cus and 0 < rest <= cus // 2
+    if total < cus:
+        want9, want13 = {9}, {2}
+    else:
+        want9, want13 = ({9, 2}, {13, 2}) if split else ({9}, {13})
+    assert ran[0] == want9 and ran[1] == want13, (ran, total)
     assert not torch.isnan(outs[1]).any()
     assert torch.equal(outs[0], outs[1])
 
@@ -844,8 +938,10 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
 
 
 def _bench_shape_forward(eng, imgs_u8, seg, onoff, labels, dev):
-    """Stage n_img x n_mask masks exactly as bench.py's step() does (image j -> slots [j*n_mask, (j+1)*n_mask)) and
-    run ONE forward over the whole batch.  -> (score f32[n_img, n_mask], pred i32[n_img, n_mask]) numpy."""
+    """Stage n_img x n_mask masks by hand (image j -> slots [j*n_mask, (j+1)*n_mask), every slot offset a multiple of n_mask)
+    and run ONE forward over the whole batch -- how bench.py's step was written up to round 2.  The bench now runs
+    MaskedForwardEngine.score_packed at forward batch 2340 (images straddle forwards): tests/test_gpu_benched_entry.py covers that
+    entry.  -> (score f32[n_img, n_mask], pred i32[n_img, n_mask]) numpy."""
     n_img, n_mask = onoff.shape[:2]
     seg_d = torch.from_numpy(seg).to(dev)
     for j in range(n_img):

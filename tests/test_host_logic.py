@@ -531,6 +531,11 @@ def test_whole_round_batch():
         assert -(-(b + 1) * 196 // 256) > tiles or whole_round_batch(limit) == b      # ... and one more image would start a new tile
         nxt = (tiles // 256 + 1) * 256 * 256 // 196
         assert nxt > limit                               # the next whole-round batch does not fit the limit
+    # another CU count (a partitioned or CU-masked device; the engine reports its own through mpx_num_cus): rounds of num_cus tiles
+    assert whole_round_batch(2400, num_cus=256) == 2340 and whole_round_batch(2400, num_cus=128) == 2340      # 14 rounds of 128
+    for cus in (64, 120, 128, 304):
+        b = whole_round_batch(2400, num_cus=cus)
+        assert b <= 2400 and -(-b * 196 // 256) % cus == 0
 
 
 def test_bench_traffic_lookup_prefers_the_benched_batch():

@@ -81,15 +81,22 @@ def _mask_worker(rank, world, port, m, out_dir):
     try:
         rng = np.random.default_rng(5)
         onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
-        score, pred = shard.score_masks_sharded(_TableEngine(), None, None, onoff, 0)
-        np.savez(os.path.join(out_dir, "m%d.npz" % rank), score=score, pred=pred)
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda out, t, *a, **k: (calls.append(int(t.numel())), real(out, t, *a, **k))[1]
+        try:
+            score, pred = shard.score_masks_sharded(_TableEngine(), None, None, onoff, 0)
+        finally:
+            dist.all_gather_into_tensor = real
+        np.savez(os.path.join(out_dir, "m%d.npz" % rank), score=score, pred=pred, collectives=np.array(calls))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("m", [24, 7, 1])
 def test_mask_axis_sharding_single_image(tmp_path, m):
-    """Config-5 shape: one image, the mask axis split over two ranks, one all-gather."""
+    """Config-5 shape: one image, the mask axis split over two ranks, ONE all-gather carrying scores and predictions
+    (SURVEY.md 8e), counted."""
     mp.spawn(_mask_worker, args=(2, _free_port(), m, str(tmp_path)), nprocs=2, join=True)
     rng = np.random.default_rng(5)
     onoff = (rng.random((m, 23)) < 0.4).astype(np.uint8)
@@ -98,7 +105,9 @@ def test_mask_axis_sharding_single_image(tmp_path, m):
     assert (single[0] == want_s).all() and (single[1] == want_p).all()
     for r in range(2):
         got = np.load(tmp_path / ("m%d.npz" % r))
+        assert got["score"].dtype == np.float32 and got["pred"].dtype == np.int32
         assert (got["score"] == want_s).all() and (got["pred"] == want_p).all()
+        assert got["collectives"].tolist() == [2 * (-(-m // 2))]            # one collective: score bits + preds of the widest block
 
 
 def _seg23():

@@ -1,6 +1,8 @@
+#!/bin/bash
+# effective clock and MFMA duty of the three block-tail launches (one rocprofv3 --pmc pass per tail)
 set -e
 export TMPDIR=/tmp
-cd /root/repo
+cd "$(dirname "$0")/.."
 O=gpurun_out/pmc_clock_tail; mkdir -p $O
 for K in 0 1 2; do
   rm -rf $O/run
