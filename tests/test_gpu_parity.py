@@ -626,7 +626,7 @@ def test_conv_persistent_patch_kernel(eng101, name, batch):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("batch", [1, 11, 41, 335, 347, 392, 700, 1013])
+@pytest.mark.parametrize("batch", [1, 11, 41, 335, 347, 523, 700, 1013])
 @pytest.mark.parametrize("name", ["layer2.1.conv1", "layer3.5.conv1", "layer4.1.conv1"])
 def test_conv_persistent_256_kernel(eng101, name, batch):
     """Tile id 13 = the 256x256 kernel as one persistent workgroup per CU (csrc/mpx_conv256p.h): the two-stage ring runs on across
@@ -634,9 +634,9 @@ def test_conv_persistent_256_kernel(eng101, name, batch):
     tile's first step (vmcnt(32) at its rendezvous).  512 -> 128 is not eligible (cout % 256).  A launch with fewer tiles than CUs
     runs on the 128x128 kernel, which sums in the same order (launch_conv256p); from one round on the persistent walk runs, and when
     a small last round is left (launch_conv: rest <= half the CUs) the images behind the whole rounds go to the 128x128 kernel too:
-    1024 -> 256 on 14x14 at 335 / 347 images = 257 / 266 tiles -> 256 persistent + the rest on tile 2; 392 images = 301 tiles and
-    700 = 536 -> all persistent, uneven tile counts per workgroup; 2048 -> 512 on 7x7 (two cout tiles) at 700 / 1013 images.  Every
-    case asserts which kernels ran.  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
+    1024 -> 256 on 14x14 at 335 / 347 / 700 images = 257 / 266 / 536 tiles -> the whole rounds persistent + the rest on tile 2; 523
+    images = 401 tiles (rest 145 > half the CUs) -> all on the persistent walk with uneven tile counts per workgroup; 2048 -> 512 on
+    7x7 (two cout tiles) at 700 images = 268 tiles (split) and 1013 = 388 (all persistent).  Every case asserts which kernels ran.  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
     sd = synth.make_state_dict("resnet101")
     i = _layer_index(eng101, name)
     d = eng101.layers[i]
