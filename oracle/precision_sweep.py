@@ -30,6 +30,7 @@ from network_interpretation_imagenet_amd import masks, segment, synth  # noqa: E
 from oracle import resnet_ref as R, scorer as S, smallnets_ref as SN  # noqa: E402
 
 GATE = 5e-5
+POLICIES = ("full", "t1_hi") + (("w2_hi",) if os.environ.get("SWEEP_W2") else ())      # SWEEP_W2=1 adds the weight-side two-product form
 
 
 def rnd(t, fmt):
@@ -48,8 +49,11 @@ class Formats:
     def __init__(self, sd64, policy):
         self.policy = policy
         self.t1_consumers = set()
+        self.hi_only_weights = set()
         if policy == "t1_hi":
             self.t1_consumers = {id(v) for k, v in sd64.items() if k.endswith(".conv2.weight")}
+        if policy == "w2_hi":       # the other two-product form: conv2's WEIGHTS as one fp16 plane, its input hi + lo
+            self.hi_only_weights = {id(v) for k, v in sd64.items() if k.endswith(".conv2.weight")}
         self.wcache = {}
 
     def __enter__(self):
@@ -60,7 +64,7 @@ class Formats:
 
         def w_of(w):
             if id(w) not in self.wcache:
-                self.wcache[id(w)] = rnd(w, "f16x2")
+                self.wcache[id(w)] = rnd(w, "f16" if id(w) in self.hi_only_weights else "f16x2")
             return self.wcache[id(w)]
 
         def conv2d(x, w, b=None, stride=1, padding=0):
@@ -115,10 +119,10 @@ def sweep_imagenet(arch, n_pic, n_mask):
         xb = torch.from_numpy(np.stack([x] + [S.apply_mask(x, S.onoff_mask_u8(seg, onoff[m])) for m in range(len(onoff))])).double()
         ref = run(fwd, sd64, xb, "f64")
         label = int(ref[0].argmax())                # row 0 = the unmasked picture (the reference's base prediction)
-        e = {p: score_err(run(fwd, sd64, xb, p)[1:], ref[1:], label) for p in ("full", "t1_hi")}
+        e = {p: score_err(run(fwd, sd64, xb, p)[1:], ref[1:], label) for p in POLICIES}
         pr = torch.softmax(ref[1:], 1)[:, label]
-        print("%-10s %-5s pic %d  S=%-4d label %-4d scores %.3f..%.3f   full %.2e   t1_hi %.2e   (%.0f s)" % (
-            arch, kind, i, onoff.shape[1], label, float(pr.min()), float(pr.max()), e["full"], e["t1_hi"], time.time() - t0), flush=True)
+        print("%-10s %-5s pic %d  S=%-4d label %-4d scores %.3f..%.3f   %s   (%.0f s)" % (
+            arch, kind, i, onoff.shape[1], label, float(pr.min()), float(pr.max()), "   ".join("%s %.2e" % (p, e[p]) for p in POLICIES), time.time() - t0), flush=True)
         for p, v in e.items():
             worst[(kind, p)] = max(worst.get((kind, p), 0.0), v)
     return worst
@@ -133,10 +137,10 @@ def sweep_cifar():
         xb = torch.from_numpy(g["pic%d/masked_inputs" % i]).double()
         label = int(g["pic%d/label" % i])
         ref = run(fwd, sd64, xb, "f64")
-        e = {p: score_err(run(fwd, sd64, xb, p), ref, label) for p in ("full", "t1_hi")}
+        e = {p: score_err(run(fwd, sd64, xb, p), ref, label) for p in POLICIES}
         pr = torch.softmax(ref, 1)[:, label]
-        print("%-10s %-5s pic %d  label %-4d scores %.3f..%.3f   full %.2e   t1_hi %.2e" % (
-            "cifar_resnet56", "trained", i, label, float(pr.min()), float(pr.max()), e["full"], e["t1_hi"]), flush=True)
+        print("%-10s %-5s pic %d  label %-4d scores %.3f..%.3f   %s" % (
+            "cifar_resnet56", "trained", i, label, float(pr.min()), float(pr.max()), "   ".join("%s %.2e" % (p, e[p]) for p in POLICIES)), flush=True)
         for p, v in e.items():
             worst[("trained", p)] = max(worst.get(("trained", p), 0.0), v)
     return worst

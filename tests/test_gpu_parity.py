@@ -1113,6 +1113,24 @@ def test_engine_errors(eng18, dev):
         eng18.score_masks(img, seg, np.ones((2, 196), dtype=np.uint8), 1000)
     o, s, p = eng18.score_masks(img, seg, np.zeros((0, 196), dtype=np.uint8), 0)   # empty batch
     assert s.shape == (0,) and p.shape == (0,)
+    # engine.heatmap_device (the per-rank step of shard.heatmap_sharded) validates like score_masks: a mismatched S or label used to
+    # come back as a silently wrong heat map (the kernels only guard their indices)
+    buf = torch.zeros(224 * 224 + 1, dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError):
+        eng18.heatmap_device(img, seg, np.ones((2, 195), dtype=np.uint8), 0, buf)       # S mismatch
+    with pytest.raises(ValueError):
+        eng18.heatmap_device(img, seg, np.ones((2, 196), dtype=np.uint8), 1000, buf)    # label out of range
+    with pytest.raises(ValueError):
+        eng18.heatmap_device(img, seg, np.ones((2, 196), dtype=np.float32), 0, buf)     # not a u8 table
+    with pytest.raises(ValueError):
+        eng18.heatmap_device(img, seg[:100], np.ones((2, 196), dtype=np.uint8), 0, buf)
+    with pytest.raises(ValueError):
+        eng18.heatmap_device(img, seg, np.ones((2, 196), dtype=np.uint8), 0, buf[:-1])
+    assert float(buf.abs().sum()) == 0.0                                                 # nothing ran
+    s_d, p_d = eng18.heatmap_device(img, seg * 3 + 5, np.ones((2, 196), dtype=np.uint8), 0, buf)     # any integer label map is ranked
+    assert s_d.shape == (2,) and float(buf[:-1].max()) <= 2.0
+    with pytest.raises(KeyError):
+        eng18.load_state_dict(synth.make_state_dict("resnet18"), only=["layer9.0.conv1"])
     labels = torch.zeros(65, dtype=torch.int32, device=dev)
     with pytest.raises(MpxError):
         eng18.forward(65, labels)                                               # > max_batch
