@@ -47,6 +47,22 @@ def masks_for(pattern):
     return a, [not x for x in a]
 
 
+SMALL = bool(os.environ.get("MPX_SMALL_TILES"))     # every wide layer on a 64-KB kernel (tiles 2 / 7): two workgroups of DIFFERENT kernels fit one CU
+
+
+def small_tiles(eng):
+    """Round 4: with the default kernels (144-160 KB of LDS) two concurrent forwards can only time-slice a CU.  On the 64-KB kernels a
+    workgroup of an HBM-bound layer of one stream and one of an MFMA-bound layer of the other can be resident together."""
+    if not SMALL:
+        return eng
+    eng.set_fusion(1)                                   # layer by layer in layer1 (the tails are 78-KB persistent workgroups)
+    for i, d in enumerate(eng.layers):
+        if d.cout <= 64 or d.name == b"fc":
+            continue
+        eng.set_conv_tile(i, 7 if (d.ksize == 1 and d.stride == 1 and d.cout > d.cin) else 2)
+    return eng
+
+
 sd = synth.make_state_dict(arch)
 img = torch.from_numpy(synth.make_images(1, kind="noise")[0]).to(dev)
 seg = torch.from_numpy(synth.grid_segments()).to(dev)
@@ -54,7 +70,7 @@ REPS = 6
 
 
 def run_single(batch):
-    eng = MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(sd)
+    eng = small_tiles(MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(sd))
     onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
     labels = torch.zeros(batch, dtype=torch.int32, device=dev)
     for _ in range(2):
@@ -72,7 +88,7 @@ def run_single(batch):
 
 
 def run_pair(pattern, batch, n_eng=2):
-    engs = [MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(sd) for _ in range(n_eng)]
+    engs = [small_tiles(MaskedForwardEngine(arch, max_batch=batch, device=0).load_state_dict(sd)) for _ in range(n_eng)]
     m = masks_for(pattern)
     streams = [masked_stream(m[0]), masked_stream(m[1])] if m else [torch.cuda.Stream(dev) for _ in range(n_eng)]
     onoff = torch.from_numpy(synth.random_onoff(batch, 196)).to(dev)
@@ -100,13 +116,13 @@ def run_pair(pattern, batch, n_eng=2):
     return n_eng * REPS * batch / dt, same
 
 
-print("%s: one engine, whole chip, batch 2048: %8.0f fwd/s" % (arch, run_single(2048)), flush=True)
-print("%s: one engine, whole chip, batch 1024: %8.0f fwd/s" % (arch, run_single(1024)), flush=True)
+print("%s%s: one engine, whole chip, batch 2340: %8.0f fwd/s" % (arch, " (64-KB kernels)" if SMALL else "", run_single(2340)), flush=True)
+print("%s: one engine, whole chip, batch 1170: %8.0f fwd/s" % (arch, run_single(1170)), flush=True)
 for pat in patterns:
     if ":" in pat:                       # "N:batch" = N engines on N unmasked streams
         n, b = (int(v) for v in pat.split(":"))
         r, same = run_pair("none", b, n)
         print("%s: %d engines x batch %d on %d plain streams: %8.0f fwd/s   (identical scores: %s)" % (arch, n, b, n, r, same), flush=True)
         continue
-    r, same = run_pair(pat, 1024)
-    print("%s: two engines x batch 1024, CU masks '%s': %8.0f fwd/s   (scores of the two engines identical: %s)" % (arch, pat, r, same), flush=True)
+    r, same = run_pair(pat, 1170)
+    print("%s: two engines x batch 1170, CU masks '%s': %8.0f fwd/s   (scores of the two engines identical: %s)" % (arch, pat, r, same), flush=True)
