@@ -22,6 +22,12 @@
 
 namespace mpx {
 
+// timing-only ablations (probe builds, wrong results; tools/ablate_convx.sh): CX_ABL bit 0 = pixel pieces, 1 = weight pieces, 2 = residual
+// loads, 3 = output stores carry an out-of-range offset -- still issued and counted, no memory access
+#ifndef CX_ABL
+#define CX_ABL 0
+#endif
+
 struct ConvX {
     static constexpr int TC = 256, TP = 128, NW = 8, NT = 512;
     static constexpr int STAGE = 49152;                 // [W_hi 16 KB | W_lo 16 KB | X_hi 8 KB | X_lo 8 KB]
@@ -81,13 +87,13 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         const int soff = f_ks * 64;
         if (which < 4) {
             const int pc = which >> 1;
-            const int voff = w_lane | f_dead;
+            const int voff = w_lane | f_dead | ((CX_ABL & 2) ? (int)OOB : 0);
             const int d = (wave * 2 + pc) * 1024;
             const int wsoff = f_ks * 1024 + (wave * 2 + pc) * 16 * K * 2;
             if ((which & 1) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, voff, wsoff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, voff, wsoff, 0, 0);
         } else {
-            const int voff = xrow | f_dead;
+            const int voff = xrow | f_dead | ((CX_ABL & 1) ? (int)OOB : 0);
             const int d = wave * 1024;
             if (which == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_hi, MPX_LDS_PTR(sb + C::OFF_XHI + d), 16, voff, soff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(x_lo, MPX_LDS_PTR(sb + C::OFF_XLO + d), 16, voff, soff, 0, 0);
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                rh[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, offA[b] + k * row8, 0, 2);
-                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, offA[b] + k * row8, 0, 2);
+                rh[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, (offA[b] + k * row8) | ((CX_ABL & 4) ? (int)OOB : 0), 0, 2);
+                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, (offA[b] + k * row8) | ((CX_ABL & 4) ? (int)OOB : 0), 0, 2);
             }
     };
     auto epilogue = [&](int ti) {               // C::EPI_STORES stores
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
                     oh[j] = hi;
                     ol[j] = lo;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[b] + k * row8, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[b] + k * row8, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, (offA[b] + k * row8) | ((CX_ABL & 8) ? (int)OOB : 0), 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, (offA[b] + k * row8) | ((CX_ABL & 8) ? (int)OOB : 0), 0, 2);
             }
         }
     };
