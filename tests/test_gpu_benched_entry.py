@@ -87,3 +87,53 @@ def test_cfg2_benched_entry_resnet18_2340_packed_vs_oracle(mpx_lib):
     """BASELINE configs[1] through the same entry: ResNet-18, 256 masks per image, 2340 slots (`bench.py --arch resnet18 --masks 256
     --images 32` packs it this way)."""
     _benched_entry_case("resnet18", 10, 256, tight=2e-5, seed=99)
+
+
+def test_cfg3_full_size_properties_resnet101_128_images_x_512_masks(mpx_lib):
+    """BASELINE configs[2] at its FULL size through the benched entry: 128 images x 512 masks = 65,536 rows in one score_packed
+    call (28 forwards of 2340 + one of 16).  The CPU loop cannot cover this size, so the checks are the size-independent ones:
+    the all-ones row of every image equals its unmasked prediction; the all-zeros row is the same bits for every image; an image
+    that appears twice (tables at different positions of different forward batches, one of them straddling a boundary) gets the
+    same bits; duplicate rows inside a table get the same bits; every score is a probability and every prediction a class; a
+    second run reproduces the first bit for bit; and 64 rows spread over the range equal a max_batch=32 engine's bits."""
+    dev = torch.device("cuda", 0)
+    arch, n_img, n_mask = "resnet101", 128, 512
+    sd = synth.make_state_dict(arch)
+    imgs = synth.make_images(n_img, seed=2024, kind="noise")
+    imgs[77] = imgs[5]                                     # the same picture twice, 72 tables apart
+    imgs[100] = imgs[4]                                    # image 4's table straddles the first forward boundary (rows 2048 .. 2559)
+    seg = synth.grid_segments()
+    onoff = synth.random_onoff(n_img * n_mask, 196, seed=2025).reshape(n_img, n_mask, 196)
+    onoff[:, 0] = 1
+    onoff[:, 1] = 0
+    onoff[:, 300] = onoff[:, 7]
+    onoff[77] = onoff[5]
+    onoff[100] = onoff[4]
+    small = MaskedForwardEngine(arch, max_batch=32, device=0).load_state_dict(sd)
+    big = MaskedForwardEngine(arch, max_batch=whole_round_batch(2400, num_cus=small.num_cus), device=0).load_state_dict(sd)
+    try:
+        base = [small.predict(imgs[j]) for j in range(n_img)]
+        labels = [b[0] for b in base]
+        labels[77], labels[100] = labels[5], labels[4]
+        score, pred = _packed(big, imgs, seg, onoff, labels, dev)
+        assert score.shape == (n_img, n_mask) and np.isfinite(score).all() and (score >= 0).all() and (score <= 1).all()
+        assert (pred >= 0).all() and (pred < 1000).all()
+        for j in range(n_img):
+            assert abs(float(score[j, 0]) - float(base[j][1][labels[j]])) < 1e-6 and pred[j, 0] == base[j][0]      # all-ones == unmasked
+        assert (pred[:, 1] == pred[0, 1]).all()                                  # all-zeros: the input is image-independent ...
+        for lab in set(labels):                                                   # ... and so are the bits of the images scored for the same class
+            same = [j for j in range(n_img) if labels[j] == lab]
+            assert (score[same, 1] == score[same[0], 1]).all()
+        assert (score[:, 300] == score[:, 7]).all() and (pred[:, 300] == pred[:, 7]).all()
+        assert (score[77] == score[5]).all() and (pred[77] == pred[5]).all()
+        assert (score[100] == score[4]).all() and (pred[100] == pred[4]).all()
+        again_s, again_p = _packed(big, imgs, seg, onoff, labels, dev)
+        assert (again_s == score).all() and (again_p == pred).all()
+        rows = [(j, m) for j in range(0, n_img, 8) for m in (2, 129, 383, 511)]                  # 64 rows over the whole range
+        for j in sorted({r[0] for r in rows}):
+            ms = [m for jj, m in rows if jj == j]
+            _o, s_small, p_small = small.score_masks(imgs[j], seg, onoff[j][ms], labels[j])
+            assert (s_small == score[j, ms]).all() and (p_small == pred[j, ms]).all(), "image %d differs from the batch-32 engine" % j
+    finally:
+        big.close()
+        small.close()
