@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 F16X3_CEILING_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three MFMA products per algorithmic product
+PEAK_F32_MFMA_TFLOPS = 157.3    # exact-f32 MFMA (v_mfma_f32_16x16x4_f32), same guide: the pipe the reference's own arithmetic type would run on
 
 
 def parse(argv=None):
@@ -378,6 +379,9 @@ def main(argv=None):
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)
                         "f16x3_ceiling": F16X3_CEILING_TFLOPS, "frac_of_f16x3_ceiling": achieved / F16X3_CEILING_TFLOPS,
                         "mfma_issued_frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS,
+                        # the same algorithmic rate against the exact-fp32 MFMA peak: what an fp32-in / fp32-accumulate conv stack (the
+                        # reference's arithmetic type) could reach at most on this chip
+                        "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                         "measured": "HIP events around every launch of one extra step after the timed region (%.2f forward batches of %d)" % (batches_profiled, batch),
                         "conv_ms_per_batch": conv_ms / max(batches_profiled, 1),
                         "timed_region_gpu_ms_per_batch": gpu_ms_timed / (args.steps * batches_per_step),
