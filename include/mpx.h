@@ -152,6 +152,23 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
                              const float mean[3], const float std[3], int slot0,
                              float* out_f32_nchw, void* stream);
 
+/* ---- K0 + stem + max pool for the masks of ONE image, by superposition ---------------------------------------
+ * replaces: the same lines as mpx_mask_apply_normalize (generate_gp_training_data_imagenet.py:598-599,234-245) AND the first
+ *           `x = self.conv1(x); x = self.bn1(x); x = self.relu(x); x = self.maxpool(x)` of model(masked_img_tensor) (:246) for
+ *           every mask of one image.  conv1 is linear and a mask is a union of superpixels, so conv1(x * mask_m) at an output pixel is
+ *           the sum, over the superpixels its 7x7 window touches, of onoff[m][s] * (the window's taps inside s) -- terms that do not
+ *           depend on the mask.  mpx_stem_table_build computes them once per image (one fp32 conv of the normalised image, taps
+ *           bucketed by label; the table lives in the engine and holds one image at a time); mpx_stem_table_apply then writes
+ *           relu(bn1(sum of the kept terms)) max-pooled 3x3 / 2 for M mask rows into the engine's pooled stem planes, slots
+ *           [slot0, slot0 + M) -- no masked image is ever materialised.  Same arguments as mpx_mask_apply_normalize (img: exactly
+ *           one of u8 HWC / f32 CHW; seg ranks in [0, S); onoff[m][s] != 0 keeps superpixel s), S <= 4096.  fp32 FMA chains in tap
+ *           order instead of the MFMA stem's split-fp16 products: equal up to rounding (~1e-7 relative).
+ * mpx_forward runs the B slots from the pooled planes when ALL of them were staged this way since they were last staged by
+ * mpx_mask_apply_normalize, from the input staging when none was, and fails (MPX_E_STATE) on a mixed batch. */
+int mpx_stem_table_build(mpx_engine* h, const uint8_t* img_u8_hwc, const float* img_f32_chw, const int32_t* seg, int S,
+                         const float mean[3], const float std[3], void* stream);
+int mpx_stem_table_apply(mpx_engine* h, const uint8_t* onoff, int M, int S, int slot0, void* stream);
+
 /* ---- K0 of the small networks: the CIFAR / MNIST scorers' mask convention ---------------------------
  * replaces: the in-place min-max rescale of the picture to [0,255] (generate_gp_training_data_cifar.py:274-279,
  *           generate_gp_training_data_mnist.py:167-171), `mask.fill(255); mask[segments == segVal] = 0` for the SELECTED
@@ -266,6 +283,9 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
 /* ---- introspection for tests / benchmarks --------------------------------------------------- */
 /* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4]. */
 int mpx_input_planes(const mpx_engine* h, void** hi, void** lo);
+/* DEV pointers of the pooled stem output planes: fp16 [max_batch][56][56][64], written by the stem + max pool launch of mpx_forward or by
+ * mpx_stem_table_apply (NULL for the small networks, which have no such stem). */
+int mpx_stem_planes(const mpx_engine* h, void** hi, void** lo);
 /* When enabled, every kernel launch of mpx_forward / mpx_mask_apply_normalize is bracketed by
  * HIP events on the launch stream (bounded pool; launches beyond it are not recorded). */
 int mpx_profile_enable(mpx_engine* h, int on);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mpx_last_conv_kernels": (_i, [_vp]),
     "mpx_pack_conv_weights": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mpx_mask_apply_normalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _fp, _fp, _i, _vp, _vp]),
+    "mpx_stem_table_build": (_i, [_vp, _vp, _vp, _vp, _i, _fp, _fp, _vp]),
+    "mpx_stem_table_apply": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mpx_conv_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_conv_dual_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_set_fusion": (_i, [_vp, _i]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "mpx_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_heatmap_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mpx_input_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mpx_stem_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mpx_profile_enable": (_i, [_vp, _i]),
     "mpx_profile_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "mpx_flops_per_forward": (C.c_double, [_vp]),

@@ -8,6 +8,7 @@
 #include "mpx_conv256p.h"
 #include "mpx_convx.h"
 #include "mpx_btail.h"
+#include "mpx_stemtab.h"
 #ifdef MPX_EXPERIMENTAL
 // Kernels that were measured in the network and did not become any layer class's default: tile ids 3 and 5 (other
 // shapes of the generic kernel), 8 (persistent kernel with a register epilogue) and 11 (pixel-stationary expanding 1x1 kernel).
@@ -39,7 +40,7 @@ constexpr size_t kActElemsPerImage = 112 * 112 * 64;   // ImageNet: largest acti
 constexpr int kSmallCPad = 32;                         // small nets: channels are stored padded to a multiple of 32
 
 enum OpKind { OP_CONV = 0, OP_MAXPOOL = 1, OP_AVGPOOL = 2, OP_HEAD = 3, OP_AVGPAD = 4, OP_BTAIL = 5 };
-enum Buf { BUF_INPUT = -1, BUF_POOL = -2, BUF_NONE = -3 };
+enum Buf { BUF_INPUT = -1, BUF_POOL = -2, BUF_NONE = -3, BUF_STEM = -4 };   // BUF_STEM: the pooled stem output (planes of its own)
 
 struct ConvLayer {
     mpx_conv_desc d;
@@ -122,6 +123,21 @@ struct mpx_engine {
     half_t* pool_lo = nullptr;
     float* logits = nullptr;
     float* seg_scratch = nullptr;   // f32[4096] per-superpixel counts (K5)
+    // the stem by superposition (mpx_stemtab.h; ImageNet ResNets): pooled stem output planes [max_batch][56][56][64] of their own (written by
+    // the stem + pool launch or by mpx_stem_table_apply), ONE image's table, the bit planes of a staging call's mask rows
+    half_t* stem_hi = nullptr;
+    half_t* stem_lo = nullptr;
+    float* stem_w32 = nullptr;      // [147][64] fp32 stem weights, tap-major
+    float* stem_s32 = nullptr;      // [64] gamma / sqrt(var + eps)
+    float* stem_t32 = nullptr;      // [64] beta - mean * scale
+    int* tab_cnt = nullptr;
+    int* tab_off = nullptr;
+    int* tab_lab = nullptr;
+    float* tab_vec = nullptr;
+    unsigned* tab_bits = nullptr;   // [4096][ceil(max_batch / 32) + 1]
+    int tab_S = -1;                 // S of the table in place (-1: none)
+    bool stem_w_loaded = false;
+    std::vector<uint8_t> slot_src;  // per input slot: 0 = never staged, 1 = K0 (input staging), 2 = stem table (pooled planes)
     std::string err;
     bool in_forward = false;
     unsigned last_kernels = 0;      // bit t: the last conv call launched the kernel of tile id t (mpx_last_conv_kernels)
@@ -222,8 +238,8 @@ int build_topology(mpx_engine* h) {
 
     int c = add_conv("conv1", "bn1", 3, 64, 7, 2, 3, 224, 1, 0);
     add_op(OP_CONV, c, BUF_INPUT, 0, BUF_NONE, 0, 0);
-    add_op(OP_MAXPOOL, -1, 0, 1, BUF_NONE, 112, 64);
-    int X = 1, cin = 64, hcur = 56;
+    add_op(OP_MAXPOOL, -1, 0, BUF_STEM, BUF_NONE, 112, 64);      // the pooled planes have a buffer of their own: nothing overwrites them
+    int X = BUF_STEM, cin = 64, hcur = 56;
     const int widths[4] = {64, 128, 256, 512};
     struct BlockRec { int c1, c2, c3, ds, hin; };
     std::vector<BlockRec> blocks;       // bottleneck blocks in forward order (the block-tail plan below is built from them)
@@ -302,7 +318,7 @@ int build_topology(mpx_engine* h) {
             std::vector<Op>& out = h->ops_bt;
             out.push_back(h->ops[0]);       // stem conv, max pool
             out.push_back(h->ops[1]);
-            int Xb = 1, T1c = -100;         // T1c: buffer of a t1 that the previous tail launch has already written
+            int Xb = BUF_STEM, T1c = -100;         // T1c: buffer of a t1 that the previous tail launch has already written
             for (size_t k = 0; k < blocks.size(); ++k) {
                 const BlockRec& R = blocks[k];
                 int T1 = T1c;
@@ -1129,7 +1145,18 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     }
     for (const TailBlock& tb : h->tails) wbytes += 2 * round_up((size_t)BT_OUT * (tb.ds >= 0 ? 2 : 1) * BT_MID * 2, 256);
     const size_t scratch_bytes = 4096 * sizeof(float);
-    const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes;
+    // the stem by superposition (ImageNet ResNets): pooled stem planes, fp32 stem weights + BatchNorm vectors, one image's table (worst case:
+    // 49 entries per conv output pixel), the bit planes of one staging call
+    const bool stemtab = stem_pool_eligible(h);
+    const int tab_nmb = (max_batch + 31) / 32 + 1;
+    const size_t stem_plane = stemtab ? round_up((size_t)max_batch * ST_POOLED * ST_POOLED * ST_C * 2, 256) : 0;
+    const size_t stem_w_bytes = stemtab ? round_up((size_t)ST_TAPS * 3 * ST_C * 4, 256) + 2 * 256 : 0;
+    const size_t tab_int_bytes = stemtab ? round_up((size_t)(ST_NPIX + 1) * 4, 256) : 0;
+    const size_t tab_lab_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * 4, 256) : 0;
+    const size_t tab_vec_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * ST_C * 4, 256) : 0;
+    const size_t tab_bits_bytes = stemtab ? round_up((size_t)4096 * tab_nmb * 4, 256) : 0;
+    const size_t stemtab_bytes = 2 * stem_plane + stem_w_bytes + 2 * tab_int_bytes + tab_lab_bytes + tab_vec_bytes + tab_bits_bytes;
+    const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes + stemtab_bytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
     h->arena_bytes = total;
@@ -1146,6 +1173,19 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     h->pool_lo = (half_t*)take(pool_plane);
     h->logits = (float*)take(logit_bytes);
     if (k0_bytes) h->k0_scratch = (float*)take(k0_bytes);
+    if (stemtab) {
+        h->stem_hi = (half_t*)take(stem_plane);
+        h->stem_lo = (half_t*)take(stem_plane);
+        h->stem_w32 = (float*)take(stem_w_bytes - 512);
+        h->stem_s32 = (float*)take(256);
+        h->stem_t32 = (float*)take(256);
+        h->tab_cnt = (int*)take(tab_int_bytes);
+        h->tab_off = (int*)take(tab_int_bytes);
+        h->tab_lab = (int*)take(tab_lab_bytes);
+        h->tab_vec = (float*)take(tab_vec_bytes);
+        h->tab_bits = (unsigned*)take(tab_bits_bytes);
+    }
+    h->slot_src.assign((size_t)max_batch, 0);
     for (ConvLayer& L : h->convs) {
         const size_t wb = round_up((size_t)L.d.cout_pad * L.d.k_packed * 2, 256);
         const size_t sb = round_up((size_t)L.d.cout_pad * 4, 256);
@@ -1273,6 +1313,23 @@ int mpx_set_conv_weights(mpx_engine* h, int i, const float* w, const float* conv
     MPX_HIP(h, hipMemcpy(L.scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     MPX_HIP(h, hipMemcpy(L.shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
     L.loaded = true;
+    if (L.is_stem && h->stem_w32) {
+        // the stem by superposition works from the fp32 tensors themselves: weights tap-major [(ky * 7 + kx) * 3 + ch][cout], the
+        // BatchNorm as y = acc * s + t with s = gamma / sqrt(var + eps), t = beta - mean * s (rounded to fp32 once)
+        std::vector<float> wt((size_t)ST_TAPS * 3 * ST_C), bs(ST_C), bt(ST_C);
+        for (int co = 0; co < ST_C; ++co) {
+            for (int ch = 0; ch < 3; ++ch)
+                for (int t = 0; t < ST_TAPS; ++t) wt[((size_t)t * 3 + ch) * ST_C + co] = w[((size_t)co * 3 + ch) * ST_TAPS + t];
+            const double sd = (double)gamma[co] / std::sqrt((double)var[co] + (double)eps);
+            bs[co] = (float)sd;
+            bt[co] = (float)((double)beta[co] - (double)mean[co] * sd);
+        }
+        MPX_HIP(h, hipMemcpy(h->stem_w32, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+        MPX_HIP(h, hipMemcpy(h->stem_s32, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+        MPX_HIP(h, hipMemcpy(h->stem_t32, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+        h->stem_w_loaded = true;
+        h->tab_S = -1;                  // a table built from the old weights is stale
+    }
     if (TailBlock* tb = tail_of_conv3(h, i)) {
         if (tb->ds < 0) {               // identity tail: the permuted copy of this layer's own planes (scale / shift are shared)
             rc = upload_tail_planes(h, *tb, hi, lo, L.d.k_packed);
@@ -1364,6 +1421,65 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
     dim3 grid((MPX_IMG * MPX_IMG + 255) / 256, (M + K0_MT - 1) / K0_MT);
     hipLaunchKernelGGL(mask_apply_normalize_kernel, grid, dim3(256), lds, st, p);
     MPX_HIP(h, hipGetLastError());
+    std::fill(h->slot_src.begin() + slot0, h->slot_src.begin() + slot0 + M, (uint8_t)1);
+    return 0;
+}
+
+int mpx_stem_table_build(mpx_engine* h, const uint8_t* img_u8_hwc, const float* img_f32_chw, const int32_t* seg, int S,
+                         const float mean[3], const float std[3], void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!h->stem_w32) return fail(h, MPX_E_STATE, "stem_table_build: this architecture has no 7x7 stem with a max pool");
+    if ((img_u8_hwc == nullptr) == (img_f32_chw == nullptr))
+        return fail(h, MPX_E_ARG, "stem_table_build: exactly one of img_u8_hwc / img_f32_chw must be given");
+    if (!seg || S <= 0 || S > 4096) return fail(h, MPX_E_ARG, "stem_table_build: null label map or S outside [1, 4096]");
+    if (img_u8_hwc && (!mean || !std)) return fail(h, MPX_E_ARG, "stem_table_build: mean/std required for u8 input");
+    if (!h->stem_w_loaded) return fail(h, MPX_E_STATE, "stem_table_build: layer 0 (%s) has no weights", h->convs[0].d.name);
+    StemTabParams p;
+    std::memset(&p, 0, sizeof p);
+    p.img_u8 = img_u8_hwc; p.img_f32 = img_f32_chw; p.seg = seg; p.S = S;
+    for (int c = 0; c < 3; ++c) {
+        p.mean[c] = mean ? mean[c] : 0.f;
+        p.std[c] = std ? std[c] : 1.f;
+    }
+    p.w = h->stem_w32; p.cnt = h->tab_cnt; p.off = h->tab_off; p.lab = h->tab_lab; p.vec = h->tab_vec;
+    MPX_SET_DEVICE(h);
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(h, st, 1, -1);
+    hipLaunchKernelGGL(stemtab_count_kernel, dim3(ST_NPIX / 4), dim3(256), 0, st, p);
+    MPX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(stemtab_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)h->tab_cnt, h->tab_off);
+    MPX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(stemtab_fill_kernel, dim3(ST_NPIX / 4), dim3(256), 0, st, p);
+    MPX_HIP(h, hipGetLastError());
+    h->tab_S = S;
+    return 0;
+}
+
+int mpx_stem_table_apply(mpx_engine* h, const uint8_t* onoff, int M, int S, int slot0, void* stream) {
+    if (!h) return MPX_E_ARG;
+    if (!h->stem_w32) return fail(h, MPX_E_STATE, "stem_table_apply: this architecture has no 7x7 stem with a max pool");
+    if (!onoff || M <= 0) return fail(h, MPX_E_ARG, "stem_table_apply: null mask rows or empty M");
+    if (h->tab_S < 0) return fail(h, MPX_E_STATE, "stem_table_apply: no table in place (mpx_stem_table_build first; loading layer 0 again discards it)");
+    if (S != h->tab_S) return fail(h, MPX_E_ARG, "stem_table_apply: S=%d, the table was built with S=%d", S, h->tab_S);
+    if (slot0 < 0 || slot0 + M > h->max_batch) return fail(h, MPX_E_STATE, "stem_table_apply: slots [%d,%d) exceed max_batch %d", slot0, slot0 + M, h->max_batch);
+    const int nmb = (M + 31) / 32;
+    MPX_SET_DEVICE(h);
+    hipStream_t st = as_stream(stream);
+    {
+        ProfScope ps(h, st, 1, -1);
+        hipLaunchKernelGGL(onoff_bitplanes_kernel, dim3((S * nmb + 255) / 256), dim3(256), 0, st, onoff, M, S, nmb, h->tab_bits);
+        MPX_HIP(h, hipGetLastError());
+    }
+    StemApplyParams p;
+    std::memset(&p, 0, sizeof p);
+    p.off = h->tab_off; p.lab = h->tab_lab; p.vec = h->tab_vec; p.bits = h->tab_bits; p.s = h->stem_s32; p.t = h->stem_t32;
+    p.out_hi = h->stem_hi; p.out_lo = h->stem_lo; p.nmb = nmb; p.M = M; p.slot0 = slot0;
+    {
+        ProfScope ps(h, st, OP_CONV, 0);        // the stem's work: booked on layer 0 like the stem + pool launch it replaces
+        hipLaunchKernelGGL(stem_apply_kernel, dim3(ST_POOLED * ST_POOLED / 4, nmb), dim3(256), 0, st, p);
+        MPX_HIP(h, hipGetLastError());
+    }
+    std::fill(h->slot_src.begin() + slot0, h->slot_src.begin() + slot0 + M, (uint8_t)2);
     return 0;
 }
 
@@ -1499,10 +1615,23 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
         ~InForward() { e->in_forward = false; }
     } scope(h);
     // (BUF_INPUT stays NULL: layer 0 reads the engine's own staging, mpx_conv_bn_act)
-    auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b >= 0 ? h->act_hi[b] : nullptr); };
-    auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b >= 0 ? h->act_lo[b] : nullptr); };
+    auto hi = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_hi : (b == BUF_STEM ? h->stem_hi : (b >= 0 ? h->act_hi[b] : nullptr)); };
+    auto lo = [&](int b) -> half_t* { return b == BUF_POOL ? h->pool_lo : (b == BUF_STEM ? h->stem_lo : (b >= 0 ? h->act_lo[b] : nullptr)); };
     int rc = 0;
     bool skip_pool = false;
+    // how the B slots were staged: by K0 into the input staging (the stem conv + max pool run here) or by mpx_stem_table_apply, which has
+    // written the pooled stem planes already (the stem and the pool are skipped).  A batch staged by both is an error, not a guess.
+    bool stem_done = false;
+    {
+        int n_tab = 0, n_k0 = 0;
+        for (int i = 0; i < B; ++i) {
+            n_tab += h->slot_src[i] == 2;
+            n_k0 += h->slot_src[i] == 1;
+        }
+        if (n_tab && n_tab != B)
+            return fail(h, MPX_E_STATE, "forward: %d of the %d slots were staged by mpx_stem_table_apply and %d by mpx_mask_apply_normalize; one forward takes one kind", n_tab, B, n_k0);
+        stem_done = n_tab == B;
+    }
     // layer1's block tails as single launches (mpx_btail.h) whenever their planes are in and no tile override asks for the
     // layer-by-layer kernels of those layers
     bool use_bt = h->fuse_bt && h->fuse_ds && tails_ready(h);
@@ -1512,6 +1641,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
     const std::vector<Op>& ops = use_bt ? h->ops_bt : h->ops;
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         const Op& o = ops[oi];
+        if (stem_done && ((o.kind == OP_CONV && o.conv == 0) || (o.kind == OP_MAXPOOL && o.out == BUF_STEM))) continue;
         switch (o.kind) {
             case OP_BTAIL:
                 rc = launch_btail(h, o.conv, hi(o.in), lo(o.in), hi(o.res), lo(o.res), hi(o.out), lo(o.out), hi(o.z), lo(o.z), B, as_stream(stream));
@@ -1638,6 +1768,13 @@ int mpx_input_planes(const mpx_engine* h, void** hi, void** lo) {
     if (!h || !hi || !lo) return MPX_E_ARG;
     *hi = h->in_hi;
     *lo = h->in_lo;
+    return 0;
+}
+
+int mpx_stem_planes(const mpx_engine* h, void** hi, void** lo) {
+    if (!h || !hi || !lo) return MPX_E_ARG;
+    *hi = h->stem_hi;               // NULL for the small networks
+    *lo = h->stem_lo;
     return 0;
 }
 

@@ -95,7 +95,11 @@ def rank_segments(segments):
 class MaskedForwardEngine:
     """One engine per process per GPU (one RCCL rank).  `arch` is the reference's `-a/--arch`."""
 
-    def __init__(self, arch="resnet101", max_batch=512, device=None):
+    def __init__(self, arch="resnet101", max_batch=512, device=None, stem=None):
+        """stem: how score_packed / score_masks / score_images stage the masks of an image on the ImageNet ResNets --
+        "table" (default): the stem by superposition (mpx_stem_table_build once per image, mpx_stem_table_apply per block of mask rows:
+        K0, the stem conv and its max pool for all masks of an image without materialising a masked image); "conv": K0 into the input
+        staging, then the MFMA stem + max pool inside the forward (rounds 1-3).  stage_masks() is always K0."""
         if arch not in ARCH_IDS:
             raise ValueError("unsupported arch %r (torchvision ResNets and the reference's small networks: %s)" % (arch, sorted(ARCH_IDS)))
         if not torch.cuda.is_available():
@@ -121,6 +125,11 @@ class MaskedForwardEngine:
         _lib.check(h, self._lib.mpx_geometry(h, *[C.byref(v) for v in g]), "mpx_geometry")
         self.image_size, self.in_channels, self.num_classes, self.logit_pitch = (int(v.value) for v in g)
         self.small = self.image_size != IMG
+        if stem not in (None, "table", "conv"):
+            raise ValueError("stem must be 'table' or 'conv', got %r" % (stem,))
+        if self.small and stem == "table":
+            raise ValueError("%s has no 7x7 stem: stem='table' is the ImageNet ResNets' path" % arch)
+        self.stem = "conv" if self.small else (stem or "table")
 
     # ---- life cycle ----
     def close(self):
@@ -216,6 +225,32 @@ class MaskedForwardEngine:
             self._h, u8, f32, _ptr(seg), _ptr(onoff), int(m), int(s), self._mean, self._std,
             int(slot0), _ptr(out_f32), self._stream()), "mpx_mask_apply_normalize")
 
+    def build_stem_table(self, image, seg, num_segments):
+        """mpx_stem_table_build: the mask-independent terms of the stem for ONE image (device u8[224,224,3] or f32[3,224,224]) and its
+        rank map (device i32[224,224], labels in [0, num_segments)); the engine holds one table at a time."""
+        for name, t in (("image", image), ("seg", seg)):
+            if t.device != self.device or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous tensor on %s" % (name, self.device))
+        if seg.dtype != torch.int32 or tuple(seg.shape) != (IMG, IMG):
+            raise ValueError("seg must be int32[%d,%d]" % (IMG, IMG))
+        if image.dtype == torch.uint8 and tuple(image.shape) == (IMG, IMG, 3):
+            u8, f32 = _ptr(image), None
+        elif image.dtype == torch.float32 and tuple(image.shape) == (3, IMG, IMG):
+            u8, f32 = None, _ptr(image)
+        else:
+            raise ValueError("image must be uint8[224,224,3] or float32[3,224,224], got %s%s" % (image.dtype, tuple(image.shape)))
+        _lib.check(self._h, self._lib.mpx_stem_table_build(self._h, u8, f32, _ptr(seg), int(num_segments), self._mean, self._std,
+                                                           self._stream()), "mpx_stem_table_build")
+
+    def apply_stem_table(self, onoff, slot0=0):
+        """mpx_stem_table_apply: the pooled stem output of M mask rows (device u8[M,S]) of the image whose table is in place, into slots
+        [slot0, slot0+M); the next forward over those slots starts behind the max pool."""
+        if onoff.device != self.device or not onoff.is_contiguous() or onoff.dtype != torch.uint8 or onoff.dim() != 2:
+            raise ValueError("onoff must be a contiguous uint8[M,S] tensor on %s" % self.device)
+        m, s = onoff.shape
+        _lib.check(self._h, self._lib.mpx_stem_table_apply(self._h, _ptr(onoff), int(m), int(s), int(slot0), self._stream()),
+                   "mpx_stem_table_apply")
+
     def forward(self, batch, labels, want_logits=False, score_out=None, pred_out=None):
         """Whole network over the staged slots [0,batch).  labels: device i32[batch].
         returns (score f32[batch], pred i32[batch][, logits f32[batch,1000]]) on the device; score_out / pred_out
@@ -255,6 +290,21 @@ class MaskedForwardEngine:
 
         return (torch.as_tensor(_View(hi.value), device=self.device),
                 torch.as_tensor(_View(lo.value), device=self.device))
+
+    def stem_planes(self, n=None):
+        """Zero-copy fp16 views (hi, lo) [n,56,56,64] of the engine-owned pooled stem output planes (ImageNet ResNets).  For tests."""
+        n = self.max_batch if n is None else int(n)
+        if self.small or not 0 < n <= self.max_batch:
+            raise ValueError("stem_planes: an ImageNet ResNet engine and n in [1, max_batch=%d]" % self.max_batch)
+        hi, lo = C.c_void_p(), C.c_void_p()
+        _lib.check(self._h, self._lib.mpx_stem_planes(self._h, C.byref(hi), C.byref(lo)), "mpx_stem_planes")
+        shape = (n, 56, 56, 64)
+
+        class _View:
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": "<f2", "version": 2}
+
+        return (torch.as_tensor(_View(hi.value), device=self.device), torch.as_tensor(_View(lo.value), device=self.device))
 
     # ---- the batched surface (SURVEY.md 8b) ----
     def _image_to_device(self, image):
@@ -354,7 +404,12 @@ class MaskedForwardEngine:
         for s0 in range(0, m, self.max_batch):
             b = min(self.max_batch, m - s0)
             labels = torch.full((b,), int(label), dtype=torch.int32, device=self.device)
-            self.stage_masks(img_d, seg_d, onoff_d[s0:s0 + b], 0)
+            if self.stem == "table":
+                if s0 == 0:
+                    self.build_stem_table(img_d, seg_d, s)
+                self.apply_stem_table(onoff_d[s0:s0 + b], 0)
+            else:
+                self.stage_masks(img_d, seg_d, onoff_d[s0:s0 + b], 0)
             out = self.forward(b, labels, want_logits=return_logits)
             score[s0:s0 + b] = out[0].cpu().numpy()
             pred[s0:s0 + b] = out[1].cpu().numpy()
@@ -382,12 +437,18 @@ class MaskedForwardEngine:
         label_rows, score_out, pred_out = label_rows.view(-1), score_out.view(-1), pred_out.view(-1)
         done = 0            # rows already handed to a forward
         used = 0            # slots staged for the next forward
+        table = self.stem == "table"
         for i in range(n):
             m, r = int(onoffs[i].shape[0]), 0
             seg = segs if shared else segs[i]
+            if table and m:
+                self.build_stem_table(images[i], seg, int(onoffs[i].shape[1]))      # once per image; its rows follow in one or two forwards
             while r < m:
                 take = min(m - r, self.max_batch - used)
-                self.stage_masks(images[i], seg, onoffs[i][r:r + take], used)
+                if table:
+                    self.apply_stem_table(onoffs[i][r:r + take], used)
+                else:
+                    self.stage_masks(images[i], seg, onoffs[i][r:r + take], used)
                 used += take
                 r += take
                 if used == self.max_batch:
