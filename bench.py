@@ -46,6 +46,9 @@ def parse(argv=None):
                     help="slots per forward batch; the mask rows of consecutive images are packed into such batches.  0 = the "
                          "largest batch <= 2400 that cuts the 14x14 maps into WHOLE rounds of tiles over the 256 CUs "
                          "(engine.whole_round_batch: 2340; at 2048 the last round of the 3x3 and reducing 1x1 layers is 1/8 full)")
+    ap.add_argument("--stem", choices=("table", "conv"), default=None,
+                    help="how the masks are staged (MaskedForwardEngine(stem=...)): 'table' = the stem by superposition (the engine's default on the "
+                         "ImageNet ResNets), 'conv' = K0 + the MFMA stem conv + max pool (rounds 1-3)")
     ap.add_argument("--cpu-masks", type=int, default=16, help="masks of the CPU baseline sample (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the all-gather even with one rank (rehearsal of the N>1 path)")
@@ -296,7 +299,7 @@ def main(argv=None):
     batch = min(batch, n_img * n_mask)
     batches_per_step = n_img * n_mask / batch          # forward batches per step (the last one of a step may be partial)
     sd = synth.make_state_dict(args.arch)
-    eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank).load_state_dict(sd)
+    eng = MaskedForwardEngine(args.arch, max_batch=batch, device=local_rank, stem=args.stem).load_state_dict(sd)
     # synthetic inputs, resident in HBM: this rank's images, the shared 14x14-block label map (S=196),
     # per-image Bernoulli(0.4) mask-vectors, labels = unmasked argmax (the reference's correctness gate)
     imgs = torch.from_numpy(synth.make_images(n_img, seed=1234 + rank, kind="noise")).to(dev)
@@ -394,7 +397,7 @@ def main(argv=None):
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
                        "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "num_cus": eng.num_cus,
-                       "entry": "MaskedForwardEngine.score_packed",
+                       "entry": "MaskedForwardEngine.score_packed", "stem": eng.stem,
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,

@@ -152,122 +152,231 @@ __global__ __launch_bounds__(256) void onoff_bitplanes_kernel(const uint8_t* __r
 }
 
 struct StemApplyParams {
-    const int* off;
-    const int* lab;
-    const float* vec;
-    const unsigned* bits;    // [S][nmb]
-    const float* s;          // BatchNorm scale gamma / sqrt(var + eps), [64]
-    const float* t;          // BatchNorm shift beta - mean * scale, [64]
-    half_t* out_hi;          // pooled planes [max_batch][56][56][64]
-    half_t* out_lo;
+    const int* __restrict__ off;
+    const int* __restrict__ lab;
+    const float* __restrict__ vec;
+    const unsigned* __restrict__ bits;    // [S][nmb]
+    const float* __restrict__ s;          // BatchNorm scale gamma / sqrt(var + eps), [64]
+    const float* __restrict__ t;          // BatchNorm shift beta - mean * scale, [64]
+    half_t* __restrict__ out_hi;          // pooled planes [max_batch][56][56][64]
+    half_t* __restrict__ out_lo;
     int nmb, M, slot0;
 };
 
-// One wave = one pooled pixel x one block of 32 masks; lane = channel.  The entries of the (up to) 3 x 3 conv pixels under the pooled
-// pixel -- per conv row ONE contiguous CSR range -- are loaded once into registers (NE of them; a pooled pixel with more runs the slow
-// path that re-reads them per mask), their keep bits of the 32 masks are one word each, and the mask loop is adds, one fma + two max
-// per conv pixel, one split and two 128-B stores.
-template <int NE>
-__device__ __forceinline__ void stem_apply_body(const StemApplyParams& p, int lane, int mcount, size_t out0, const int (&rb)[3][4],
-                                                const int (&rlen)[3], int n_e, int n_empty, float sc, float sh, int mb) {
-    float R[NE];
-    unsigned kb[NE];
-    unsigned long long starts = 0;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        // entry i of the pooled pixel = entry g of the table: rows in order, each row one contiguous range
-        int g = -1, r = 0, j = i;
-        if (j < rlen[0]) { g = rb[0][0] + j; r = 0; }
-        else if ((j -= rlen[0]) < rlen[1]) { g = rb[1][0] + j; r = 1; }
-        else if ((j -= rlen[1]) < rlen[2]) { g = rb[2][0] + j; r = 2; }
-        const bool ok = i < n_e;
-        R[i] = ok ? p.vec[(size_t)g * ST_C + lane] : 0.f;
-        const int label = ok ? p.lab[g] : 0;
-        kb[i] = ok ? p.bits[(size_t)label * p.nmb + mb] : 0u;
-        if (ok && (g == rb[r][0] || g == rb[r][1] || g == rb[r][2])) starts |= 1ull << i;     // first entry of a conv pixel
+// The four waves of a workgroup hold four neighbouring pooled pixels: their values of FOUR masks meet in LDS, then wave w writes mask
+// 4g + w -- each plane's 512 bytes (four whole lines) with one store.  (A wave's own 128 bytes per plane and mask are 14.7 M
+// two-byte-per-lane stores per forward batch, which the texture addresser serialises: 3.1 ms for the launch, as long as the MFMA stem.)
+// One barrier per four masks, two buffers: a buffer is rewritten two groups later, and the barrier in between needs every wave to have
+// read it.  Every wave of the workgroup calls this once per mask, in order.
+__device__ __forceinline__ void stem_store4(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int m, int mcount, int wave, int lane,
+                                            float best, size_t out0_row) {
+    half_t hi, lo;
+    split_f32(best, hi, lo);
+    s_out[(m >> 2) & 1][m & 3][wave][lane] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    if ((m & 3) != 3 && m != mcount - 1) return;
+    __syncthreads();
+    const int ms = (m & ~3) + wave;             // the mask this wave writes
+    if (ms < mcount) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u4 q = *(const u4*)&s_out[(m >> 2) & 1][ms & 3][lane >> 4][(lane & 15) * 4];
+        u2 vh, vl;
+        vh[0] = (q[0] & 0xffffu) | (q[1] << 16);
+        vh[1] = (q[2] & 0xffffu) | (q[3] << 16);
+        vl[0] = (q[0] >> 16) | (q[1] & 0xffff0000u);
+        vl[1] = (q[2] >> 16) | (q[3] & 0xffff0000u);
+        const size_t o = out0_row + (size_t)ms * ST_POOLED * ST_POOLED * ST_C + (size_t)(lane >> 4) * ST_C + (lane & 15) * 4;
+        __builtin_nontemporal_store(vh, (u2*)(p.out_hi + o));
+        __builtin_nontemporal_store(vl, (u2*)(p.out_lo + o));
     }
+}
+
+// One wave = one pooled pixel x one block of 32 masks; lane = channel.  The entries of the (up to) 3 x 3 conv pixels under the pooled
+// pixel are per conv row ONE contiguous CSR range.
+struct StemRows {           // the three conv rows under a pooled pixel: CSR range [a, a + l) and the starts of its (up to) three pixels
+    int a0, l0, a1, l1, a2, l2;
+    int o00, o01, o02, o10, o11, o12, o20, o21, o22;
+};
+
+__device__ __forceinline__ void stem_entry(const StemRows& w, int i, int& g, bool& start) {
+    if (i < w.l0) {
+        g = w.a0 + i;
+        start = g == w.o00 || g == w.o01 || g == w.o02;
+    } else if (i < w.l0 + w.l1) {
+        g = w.a1 + (i - w.l0);
+        start = g == w.o10 || g == w.o11 || g == w.o12;
+    } else {
+        g = w.a2 + (i - w.l0 - w.l1);
+        start = g == w.o20 || g == w.o21 || g == w.o22;
+    }
+}
+
+// General path (border pixels, conv pixels with more than four entries, any label map): the entries are streamed through registers 32 at
+// a time and EIGHT masks are carried at once -- per mask the running sum of the open conv pixel and the running pool maximum -- so a
+// pooled pixel with any number of entries runs at register speed (an earlier version re-read the table per mask for the long ones: three
+// dependent loads per entry, and the few waves that took that path set the launch's duration).  Lane i of a chunk holds the keep bits of
+// its entry i; a conv pixel's end is a branch on the scalar unit (see the asm below).
+constexpr int SA_CH = 32, SA_MG = 8;
+
+__device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int wave, int lane, int mcount,
+                                                  size_t out0_row, const StemRows& w, int n_e, int n_empty, float sc, float sh, int mb) {
     const float y_empty = fmaxf(sh, 0.f);       // a conv pixel none of whose taps lies in a kept superpixel: relu(bn(0))
-    for (int m = 0; m < mcount; ++m) {
-        float best = n_empty > 0 ? y_empty : -INFINITY;
-        float v = 0.f;
+    for (int mg = 0; mg < mcount; mg += SA_MG) {
+        float v[SA_MG], best[SA_MG];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if (i < n_e) {          // wave-uniform
-                if (i > 0 && (starts >> i & 1)) {
-                    best = fmaxf(best, fmaxf(fmaf(v, sc, sh), 0.f));
-                    v = 0.f;
+        for (int j = 0; j < SA_MG; ++j) {
+            v[j] = 0.f;
+            best[j] = n_empty > 0 ? y_empty : -INFINITY;
+        }
+        for (int cb = 0; cb < n_e; cb += SA_CH) {
+            const int cnt = min(SA_CH, n_e - cb);
+            float R[SA_CH];
+            unsigned starts = 0;
+#pragma unroll
+            for (int i = 0; i < SA_CH; ++i) {
+                int g = 0;
+                bool st = false;
+                stem_entry(w, cb + i, g, st);
+                const bool ok = i < cnt;
+                R[i] = ok ? p.vec[(size_t)g * ST_C + lane] : 0.f;
+                if (ok && st && cb + i > 0) starts |= 1u << i;
+            }
+            unsigned kbv = 0;                   // lane i: the keep bits (32 masks) of entry cb + i
+            if (lane < cnt) {
+                int g = 0;
+                bool st = false;
+                stem_entry(w, cb + lane, g, st);
+                kbv = p.bits[(size_t)p.lab[g] * p.nmb + mb];
+            }
+#pragma unroll
+            for (int j = 0; j < SA_MG; ++j) {
+                const float kfv = (kbv >> (mg + j) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int i = 0; i < SA_CH; ++i) {
+                    if (i < cnt) {              // wave-uniform
+                        if (starts >> i & 1) {
+                            // (the empty asm keeps this a BRANCH on the scalar unit: if-converted, every entry would pay the fma + max3
+                            // of a conv pixel's end and two selects -- six vector instructions per entry instead of two)
+                            asm volatile("" ::: "memory");
+                            best[j] = fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f));
+                            v[j] = 0.f;
+                        }
+                        // 1.0 * R + v and 0.0 * R + v are exact for finite R
+                        v[j] = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(kfv), i)), R[i], v[j]);
+                    }
                 }
-                v += (kb[i] >> m & 1) ? R[i] : 0.f;
             }
         }
-        if (n_e > 0) best = fmaxf(best, fmaxf(fmaf(v, sc, sh), 0.f));
-        half_t hi, lo;
-        split_f32(best, hi, lo);
-        const size_t o = out0 + (size_t)m * ST_POOLED * ST_POOLED * ST_C + lane;
-        p.out_hi[o] = hi;
-        p.out_lo[o] = lo;
+#pragma unroll
+        for (int j = 0; j < SA_MG; ++j) {
+            if (mg + j < mcount) {              // every wave of the workgroup stores every mask once: the barrier inside counts on it
+                const float b = n_e > 0 ? fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f)) : best[j];
+                stem_store4(p, s_out, mg + j, mcount, wave, lane, b, out0_row);
+            }
+        }
+    }
+}
+
+// Fast path: a pooled pixel away from the top / left border (all 3 x 3 conv pixels valid) whose conv pixels have at most KPP entries each
+// (KPP = 1, 2, 4: the window of a conv pixel inside one superpixel, across one boundary, at a corner of a grid).  Slot (q, k) = entry k of
+// conv pixel q, or a zero: fully static code, one fma per slot, one fma + max3 per conv pixel.  The 0.0 / 1.0 keep factors of the 32 masks
+// are laid out once per wave in LDS ([mask][slot]) and come back four slots per broadcast ds_read_b128: extracting them per mask on the
+// scalar unit (s_and, s_cmp, s_cselect per slot) made the launch scalar-bound at 3 x the time of its vector instructions.
+constexpr int SA_KF_PITCH = 40;                 // floats per mask row: 36 slots, 16-byte aligned rows
+
+template <int KPP>
+__device__ __forceinline__ void stem_apply_fast(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float (*s_kf)[SA_KF_PITCH], int wave,
+                                                int lane, int mcount, size_t out0_row, const int (&o)[9], const int (&len)[9], float sc, float sh,
+                                                int mb) {
+    constexpr int NS = 9 * KPP, NS4 = (NS + 3) / 4 * 4;
+    float R[NS4];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int k = 0; k < KPP; ++k) {
+            const bool ok = k < len[q];
+            const int g = o[q] + k;
+            R[q * KPP + k] = ok ? p.vec[(size_t)g * ST_C + lane] : 0.f;
+            const unsigned kb = ok ? p.bits[(size_t)p.lab[g] * p.nmb + mb] : 0u;       // wave-uniform
+            if (lane < 32) s_kf[lane][q * KPP + k] = (kb >> lane & 1u) ? 1.0f : 0.0f;  // lane = mask
+        }
+#pragma unroll
+    for (int i = NS; i < NS4; ++i) {
+        R[i] = 0.f;
+        if (lane < 32) s_kf[lane][i] = 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int m = 0; m < mcount; ++m) {
+        f4 kf[NS4 / 4];
+#pragma unroll
+        for (int i = 0; i < NS4 / 4; ++i) kf[i] = *(const f4*)&s_kf[m][4 * i];      // the same address in every lane: a broadcast
+        float best = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < KPP; ++k)       // 1.0 * R + v and 0.0 * R + v are exact for finite R
+                v = fmaf(kf[(q * KPP + k) / 4][(q * KPP + k) % 4], R[q * KPP + k], v);
+            best = fmaxf(best, fmaxf(fmaf(v, sc, sh), 0.f));
+        }
+        stem_store4(p, s_out, m, mcount, wave, lane, best, out0_row);
     }
 }
 
 __global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned s_out[2][4][4][ST_C];
+    __shared__ __attribute__((aligned(16))) float s_kf[4][32][SA_KF_PITCH];         // per wave: [mask][slot] keep factors of the fast path
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int P = blockIdx.x * 4 + wave;                        // pooled pixel (3136 = 784 * 4)
+    const int P = blockIdx.x * 4 + wave;                        // pooled pixel (3136 = 784 * 4): the workgroup's four are neighbours in a row
     const int mb = blockIdx.y;
     const int m0 = mb * 32;
     const int mcount = min(32, p.M - m0);
     const int py = P / ST_POOLED, px = P - py * ST_POOLED;
-    // valid conv columns / rows under the pooled pixel (3x3 window, stride 2, pad 1)
-    const int cx0 = max(2 * px - 1, 0), cx1 = min(2 * px + 1, ST_CONV - 1);
-    const int ncol = cx1 - cx0 + 1;
-    int rb[3][4], rlen[3];                                      // per conv row: the CSR boundaries of its (up to 3) pixels, entries in the row
-    int n_e = 0, n_empty = 0;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int cy = 2 * py - 1 + dy;
-        const bool row_ok = (unsigned)cy < (unsigned)ST_CONV;
-        const int q0 = (row_ok ? cy : 0) * ST_CONV + cx0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rb[dy][j] = p.off[q0 + min(j, ncol)];
-        if (!row_ok) {
-#pragma unroll
-            for (int j = 1; j < 4; ++j) rb[dy][j] = rb[dy][0];
-        }
-        rlen[dy] = rb[dy][3] - rb[dy][0];
-        n_e += rlen[dy];
-        if (row_ok)
-            for (int j = 0; j < ncol; ++j) n_empty += rb[dy][j + 1] == rb[dy][j];
-        // a boundary that is not the start of a pixel of this row must not be taken for one: pixels beyond ncol repeat the end offset,
-        // which no entry of the row equals (entries are < the end offset)
+    // valid conv columns under the pooled pixel (3x3 window, stride 2, pad 1): 2px-1 .. 2px+1 clipped on the left (2 * 55 + 1 = 111 fits)
+    const int cx0 = max(2 * px - 1, 0);
+    const int ncol = 2 * px + 1 - cx0 + 1;                      // 2 or 3
+    StemRows w;
+    int n_empty = 0;
+    {
+        // row r = conv row 2py - 1 + r; rows outside the map (r = 0 for py = 0) are empty
+        const int cy0 = 2 * py - 1, cy1 = 2 * py, cy2 = 2 * py + 1;
+        const bool ok0 = cy0 >= 0;
+        const int q0 = (ok0 ? cy0 : 0) * ST_CONV + cx0, q1 = cy1 * ST_CONV + cx0, q2 = cy2 * ST_CONV + cx0;
+        const int e00 = p.off[q0], e01 = p.off[q0 + 1], e02 = p.off[q0 + 2], e03 = p.off[q0 + ncol];
+        const int e10 = p.off[q1], e11 = p.off[q1 + 1], e12 = p.off[q1 + 2], e13 = p.off[q1 + ncol];
+        const int e20 = p.off[q2], e21 = p.off[q2 + 1], e22 = p.off[q2 + 2], e23 = p.off[q2 + ncol];
+        // (with two columns e_2 is the end offset, which no entry of the row equals: never taken for a start)
+        w.a0 = e00; w.l0 = ok0 ? e03 - e00 : 0; w.o00 = e00; w.o01 = e01; w.o02 = e02;
+        w.a1 = e10; w.l1 = e13 - e10; w.o10 = e10; w.o11 = e11; w.o12 = e12;
+        w.a2 = e20; w.l2 = e23 - e20; w.o20 = e20; w.o21 = e21; w.o22 = e22;
+        if (ok0) n_empty += (e01 == e00) + (e02 == e01) + (ncol == 3 && e03 == e02);
+        n_empty += (e11 == e10) + (e12 == e11) + (ncol == 3 && e13 == e12);
+        n_empty += (e21 == e20) + (e22 == e21) + (ncol == 3 && e23 == e22);
     }
+    const int n_e = w.l0 + w.l1 + w.l2;
     const float sc = p.s[lane], sh = p.t[lane];
-    const size_t out0 = (((size_t)(p.slot0 + m0) * ST_POOLED + py) * ST_POOLED + px) * ST_C;
-    if (n_e <= 20) {
-        stem_apply_body<20>(p, lane, mcount, out0, rb, rlen, n_e, n_empty, sc, sh, mb);
-    } else if (n_e <= 44) {
-        stem_apply_body<44>(p, lane, mcount, out0, rb, rlen, n_e, n_empty, sc, sh, mb);
+    const size_t out0_row = (((size_t)(p.slot0 + m0) * ST_POOLED + py) * ST_POOLED + (px - wave)) * ST_C;
+    // the per-pixel view of the same ranges for the fast path
+    const int o9[9] = {w.o00, w.o01, w.o02, w.o10, w.o11, w.o12, w.o20, w.o21, w.o22};
+    const int end9[3] = {w.a0 + w.l0, w.a1 + w.l1, w.a2 + w.l2};
+    int len9[9], kmax = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        len9[q] = ((q % 3 == 2) ? end9[q / 3] : o9[q + 1]) - o9[q];
+        kmax = max(kmax, len9[q]);
+    }
+    const bool interior = py > 0 && px > 0;             // all nine conv pixels inside the map (ncol = 3, row 0 valid)
+    if (interior && kmax <= 1) {
+        stem_apply_fast<1>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
+    } else if (interior && kmax <= 2) {
+        stem_apply_fast<2>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
+    } else if (interior && kmax <= 4) {
+        stem_apply_fast<4>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
     } else {
-        // slow path (label maps with many superpixels under one window): the entries are re-read for every mask
-        const float y_empty = fmaxf(sh, 0.f);
-        for (int m = 0; m < mcount; ++m) {
-            float best = n_empty > 0 ? y_empty : -INFINITY;
-            for (int dy = 0; dy < 3; ++dy)
-                for (int j = 0; j < 3; ++j) {
-                    const int e0 = rb[dy][j], e1 = rb[dy][j + 1];
-                    if (e1 == e0) continue;
-                    float v = 0.f;
-                    for (int e = e0; e < e1; ++e) {
-                        const unsigned k = p.bits[(size_t)p.lab[e] * p.nmb + mb];
-                        v += (k >> m & 1) ? p.vec[(size_t)e * ST_C + lane] : 0.f;
-                    }
-                    best = fmaxf(best, fmaxf(fmaf(v, sc, sh), 0.f));
-                }
-            half_t hi, lo;
-            split_f32(best, hi, lo);
-            const size_t o = out0 + (size_t)m * ST_POOLED * ST_POOLED * ST_C + lane;
-            p.out_hi[o] = hi;
-            p.out_lo[o] = lo;
-        }
+        stem_apply_stream(p, s_out, wave, lane, mcount, out0_row, w, n_e, n_empty, sc, sh, mb);
     }
 }
 

@@ -98,8 +98,9 @@ class MaskedForwardEngine:
     def __init__(self, arch="resnet101", max_batch=512, device=None, stem=None):
         """stem: how score_packed / score_masks / score_images stage the masks of an image on the ImageNet ResNets --
         "table" (default): the stem by superposition (mpx_stem_table_build once per image, mpx_stem_table_apply per block of mask rows:
-        K0, the stem conv and its max pool for all masks of an image without materialising a masked image); "conv": K0 into the input
-        staging, then the MFMA stem + max pool inside the forward (rounds 1-3).  stage_masks() is always K0."""
+        K0, the stem conv and its max pool for all masks of an image without materialising a masked image) whenever a call brings at
+        least `stem_table_min_rows` (96) rows per image, K0 + the MFMA stem otherwise (a BO round's 28 .. 118 windows); "conv": always
+        K0 into the input staging, then the MFMA stem + max pool inside the forward (rounds 1-3).  stage_masks() is always K0."""
         if arch not in ARCH_IDS:
             raise ValueError("unsupported arch %r (torchvision ResNets and the reference's small networks: %s)" % (arch, sorted(ARCH_IDS)))
         if not torch.cuda.is_available():
@@ -125,6 +126,9 @@ class MaskedForwardEngine:
         _lib.check(h, self._lib.mpx_geometry(h, *[C.byref(v) for v in g]), "mpx_geometry")
         self.image_size, self.in_channels, self.num_classes, self.logit_pitch = (int(v.value) for v in g)
         self.small = self.image_size != IMG
+        # below this many mask rows per image the table does not pay: building it costs what K0 + the MFMA stem cost for ~40 masks, and
+        # a short apply launch leaves the chip half empty (tools/stem_bench.py: 37 rows per image 8.0 against 3.9 ms per 2340 rows)
+        self.stem_table_min_rows = 96
         if stem not in (None, "table", "conv"):
             raise ValueError("stem must be 'table' or 'conv', got %r" % (stem,))
         if self.small and stem == "table":
@@ -404,7 +408,7 @@ class MaskedForwardEngine:
         for s0 in range(0, m, self.max_batch):
             b = min(self.max_batch, m - s0)
             labels = torch.full((b,), int(label), dtype=torch.int32, device=self.device)
-            if self.stem == "table":
+            if self.stem == "table" and m >= self.stem_table_min_rows:
                 if s0 == 0:
                     self.build_stem_table(img_d, seg_d, s)
                 self.apply_stem_table(onoff_d[s0:s0 + b], 0)
@@ -437,7 +441,8 @@ class MaskedForwardEngine:
         label_rows, score_out, pred_out = label_rows.view(-1), score_out.view(-1), pred_out.view(-1)
         done = 0            # rows already handed to a forward
         used = 0            # slots staged for the next forward
-        table = self.stem == "table"
+        # one kind of staging per call (a forward takes its slots from ONE of the two): the table when the images bring enough rows each
+        table = self.stem == "table" and total >= self.stem_table_min_rows * max(1, sum(1 for o in onoffs if int(o.shape[0])))
         for i in range(n):
             m, r = int(onoffs[i].shape[0]), 0
             seg = segs if shared else segs[i]

@@ -45,7 +45,7 @@ def _segments(kind, golden_dir):
 
 def _oracle_pooled(sd, img, seg, onoff):
     """fp64: normalise, mask, conv1 + bn1 + relu + maxpool(3, 2, 1)  -> [M,56,56,64]"""
-    x = torch.from_numpy(scorer.to_tensor_normalize(img)).double()
+    x = torch.as_tensor(scorer.to_tensor_normalize(img)).double()
     keep = torch.from_numpy(onoff.astype(np.float64))[:, torch.from_numpy(seg.astype(np.int64))]          # [M,224,224]
     xb = x[None] * keep[:, None]
     y = F.conv2d(xb, sd["conv1.weight"].double(), None, 2, 3)
@@ -170,6 +170,7 @@ def test_table_stem_engine_vs_conv_stem_engine_vs_cpu_loop(mpx_lib, arch, tight)
     conv = MaskedForwardEngine(arch, max_batch=24, device=0, stem="conv").load_state_dict(sd)
     try:
         assert tab.stem == "table" and conv.stem == "conv"
+        tab.stem_table_min_rows = 1              # 40 rows: below the default threshold of 96 rows per image
         label = tab.predict(img)[0]
         assert conv.predict(img)[0] == label
         _o, s_t, p_t = tab.score_masks(img, seg, onoff, label)
