@@ -215,10 +215,10 @@ __device__ __forceinline__ void stem_entry(const StemRows& w, int i, int& g, boo
 // a time and EIGHT masks are carried at once -- per mask the running sum of the open conv pixel and the running pool maximum -- so a
 // pooled pixel with any number of entries runs at register speed (an earlier version re-read the table per mask for the long ones: three
 // dependent loads per entry, and the few waves that took that path set the launch's duration).  Lane i of a chunk holds the keep bits of
-// its entry i; a conv pixel's end is a branch on the scalar unit (see the asm below).
+// its entry i and lays the eight masks' factors out in LDS; a conv pixel's end is a branch on the scalar unit (see the asm below).
 constexpr int SA_CH = 32, SA_MG = 8;
 
-__device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int wave, int lane, int mcount,
+__device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float* s_ks, int wave, int lane, int mcount,
                                                   size_t out0_row, const StemRows& w, int n_e, int n_empty, float sc, float sh, int mb) {
     const float y_empty = fmaxf(sh, 0.f);       // a conv pixel none of whose taps lies in a kept superpixel: relu(bn(0))
     for (int mg = 0; mg < mcount; mg += SA_MG) {
@@ -248,21 +248,34 @@ __device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsi
                 stem_entry(w, cb + lane, g, st);
                 kbv = p.bits[(size_t)p.lab[g] * p.nmb + mb];
             }
+            // the 0.0 / 1.0 keep factors of the group's eight masks for the chunk's entries, [mask][entry] in the wave's LDS slice; they come
+            // back four entries per broadcast ds_read_b128
+            __builtin_amdgcn_wave_barrier();    // the previous chunk's reads are done
+            if (lane < SA_CH) {
+#pragma unroll
+                for (int j = 0; j < SA_MG; ++j) s_ks[j * SA_CH + lane] = (kbv >> (mg + j) & 1u) ? 1.0f : 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int j = 0; j < SA_MG; ++j) {
-                const float kfv = (kbv >> (mg + j) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
-                for (int i = 0; i < SA_CH; ++i) {
-                    if (i < cnt) {              // wave-uniform
-                        if (starts >> i & 1) {
-                            // (the empty asm keeps this a BRANCH on the scalar unit: if-converted, every entry would pay the fma + max3
-                            // of a conv pixel's end and two selects -- six vector instructions per entry instead of two)
-                            asm volatile("" ::: "memory");
-                            best[j] = fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f));
-                            v[j] = 0.f;
+                for (int i4 = 0; i4 < SA_CH / 4; ++i4) {
+                    const f4 kf = *(const f4*)&s_ks[j * SA_CH + 4 * i4];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = 4 * i4 + ii;
+                        if (i < cnt) {          // wave-uniform
+                            if (starts >> i & 1) {
+                                // (the empty asm keeps this a BRANCH on the scalar unit: if-converted, every entry would pay the fma + max3
+                                // of a conv pixel's end and two selects -- six vector instructions per entry instead of two)
+                                asm volatile("" ::: "memory");
+                                best[j] = fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f));
+                                v[j] = 0.f;
+                            }
+                            v[j] = fmaf(kf[ii], R[i], v[j]);       // 1.0 * R + v and 0.0 * R + v are exact for finite R
                         }
-                        // 1.0 * R + v and 0.0 * R + v are exact for finite R
-                        v[j] = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(kfv), i)), R[i], v[j]);
                     }
                 }
             }
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p
     } else if (interior && kmax <= 4) {
         stem_apply_fast<4>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
     } else {
-        stem_apply_stream(p, s_out, wave, lane, mcount, out0_row, w, n_e, n_empty, sc, sh, mb);
+        stem_apply_stream(p, s_out, &s_kf[wave][0][0], wave, lane, mcount, out0_row, w, n_e, n_empty, sc, sh, mb);
     }
 }
 

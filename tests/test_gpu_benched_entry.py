@@ -119,7 +119,8 @@ def test_cfg3_full_size_properties_resnet101_128_images_x_512_masks(mpx_lib):
         assert score.shape == (n_img, n_mask) and np.isfinite(score).all() and (score >= 0).all() and (score <= 1).all()
         assert (pred >= 0).all() and (pred < 1000).all()
         for j in range(n_img):
-            assert abs(float(score[j, 0]) - float(base[j][1][labels[j]])) < 1e-6 and pred[j, 0] == base[j][0]      # all-ones == unmasked
+            # all-ones == unmasked (predict stages its one row through K0 and the MFMA stem, the tables go through the stem table: rounding)
+            assert abs(float(score[j, 0]) - float(base[j][1][labels[j]])) < 2e-6 and pred[j, 0] == base[j][0]
         assert (pred[:, 1] == pred[0, 1]).all()                                  # all-zeros: the input is image-independent ...
         for lab in set(labels):                                                   # ... and so are the bits of the images scored for the same class
             same = [j for j in range(n_img) if labels[j] == lab]
@@ -130,6 +131,7 @@ def test_cfg3_full_size_properties_resnet101_128_images_x_512_masks(mpx_lib):
         again_s, again_p = _packed(big, imgs, seg, onoff, labels, dev)
         assert (again_s == score).all() and (again_p == pred).all()
         rows = [(j, m) for j in range(0, n_img, 8) for m in (2, 129, 383, 511)]                  # 64 rows over the whole range
+        small.stem_table_min_rows = 1           # four rows per call: stage them the way the tables were staged (bits are compared)
         for j in sorted({r[0] for r in rows}):
             ms = [m for jj, m in rows if jj == j]
             _o, s_small, p_small = small.score_masks(imgs[j], seg, onoff[j][ms], labels[j])

@@ -893,7 +893,7 @@ def test_properties_full_batch(eng18):
     _o, s0, p0, lg0 = eng18.score_masks(imgs[0], seg, onoff, label, return_logits=True)
     _o, s1, _p1 = eng18.score_masks(imgs[1], seg, onoff, label)
     base_pred, base_prob = eng18.predict(imgs[0])
-    assert s0[0] == base_prob[label] or abs(s0[0] - base_prob[label]) < 1e-7     # all-ones mask == unmasked
+    assert abs(s0[0] - base_prob[label]) < 2e-6     # all-ones mask == unmasked (one row through the MFMA stem, 150 through the stem table)
     assert p0[0] == base_pred
     assert s0[1] == s1[1]                                   # all-zeros mask: independent of the image
     assert s0[3] == s0[70] == s0[149] and p0[3] == p0[70]   # batch/slot invariance, bit for bit
@@ -921,7 +921,8 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
         base_pred, base_prob = eng.predict(imgs[0])
         _o, s0, p0, lg = eng.score_masks(imgs[0], seg, onoff, base_pred, return_logits=True)
         _o, s1, _p = eng.score_masks(imgs[1], seg, onoff, base_pred)
-        assert abs(s0[0] - base_prob[base_pred]) < 1e-6 and p0[0] == base_pred     # all-ones == unmasked
+        assert abs(s0[0] - base_prob[base_pred]) < 2e-6 and p0[0] == base_pred     # all-ones == unmasked (predict stages one row through K0 and
+                                                                                   # the MFMA stem, 512 rows go through the stem table: rounding)
         assert s0[1] == s1[1]                                                      # all-zeros: image-independent
         assert s0[7] == s0[300] == s0[511]                                         # slot invariance, bit for bit
         assert np.isfinite(lg).all() and (lg.argmax(1) == p0).all()
@@ -930,6 +931,7 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
         assert np.abs(sm[np.arange(512), base_pred] - s0).max() < 1e-6
         # the same masks through a smaller engine (different batch -> different tile rounds) agree bit for bit
         small = MaskedForwardEngine("resnet101", max_batch=24, device=0).load_state_dict(synth.make_state_dict("resnet101"))
+        small.stem_table_min_rows = 1           # 48 rows: stage them the way the 512 were staged (bits are compared)
         _o, s_small, p_small = small.score_masks(imgs[0], seg, onoff[:48], base_pred)
         small.close()
         assert (s_small == s0[:48]).all() and (p_small == p0[:48]).all()
@@ -963,8 +965,10 @@ def test_cfg3_benched_shape_resnet101_2048_vs_oracle(mpx_lib, dev):
     imgs = synth.make_images(n_img, seed=1234, kind="noise")
     seg = synth.grid_segments()
     onoff = synth.random_onoff(n_img * n_mask, 196, seed=4321).reshape(n_img, n_mask, 196)
-    small = MaskedForwardEngine(arch, max_batch=32, device=0).load_state_dict(sd)
-    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0).load_state_dict(sd)
+    # (staged by hand through K0: both engines on the MFMA stem -- the stem by superposition rounds differently, its bits are compared
+    # with its own in tests/test_gpu_benched_entry.py)
+    small = MaskedForwardEngine(arch, max_batch=32, device=0, stem="conv").load_state_dict(sd)
+    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0, stem="conv").load_state_dict(sd)
     try:
         labels = [small.predict(imgs[j])[0] for j in range(n_img)]
         score, pred = _bench_shape_forward(big, imgs, seg, onoff, labels, dev)
@@ -996,8 +1000,8 @@ def test_cfg2_resnet18_256_masks_per_image_in_one_batch(mpx_lib, dev):
     seg = synth.grid_segments()
     onoff = synth.random_onoff(n_img * n_mask, 196, seed=17).reshape(n_img, n_mask, 196)
     onoff[3, 100] = onoff[3, 7]                    # duplicate rows inside an image
-    small = MaskedForwardEngine(arch, max_batch=64, device=0).load_state_dict(sd)
-    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0).load_state_dict(sd)
+    small = MaskedForwardEngine(arch, max_batch=64, device=0, stem="conv").load_state_dict(sd)       # hand staging through K0: the MFMA stem on both
+    big = MaskedForwardEngine(arch, max_batch=n_img * n_mask, device=0, stem="conv").load_state_dict(sd)
     try:
         labels = [small.predict(imgs[j])[0] for j in range(n_img)]
         score, pred = _bench_shape_forward(big, imgs, seg, onoff, labels, dev)
