@@ -120,7 +120,7 @@ def test_cfg3_full_size_properties_resnet101_128_images_x_512_masks(mpx_lib):
         assert (pred >= 0).all() and (pred < 1000).all()
         for j in range(n_img):
             # all-ones == unmasked (predict stages its one row through K0 and the MFMA stem, the tables go through the stem table: rounding)
-            assert abs(float(score[j, 0]) - float(base[j][1][labels[j]])) < 2e-6 and pred[j, 0] == base[j][0]
+            assert abs(float(score[j, 0]) - float(base[j][1][labels[j]])) < 1e-5 and pred[j, 0] == base[j][0]
         assert (pred[:, 1] == pred[0, 1]).all()                                  # all-zeros: the input is image-independent ...
         for lab in set(labels):                                                   # ... and so are the bits of the images scored for the same class
             same = [j for j in range(n_img) if labels[j] == lab]

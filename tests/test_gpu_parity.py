@@ -893,7 +893,7 @@ def test_properties_full_batch(eng18):
     _o, s0, p0, lg0 = eng18.score_masks(imgs[0], seg, onoff, label, return_logits=True)
     _o, s1, _p1 = eng18.score_masks(imgs[1], seg, onoff, label)
     base_pred, base_prob = eng18.predict(imgs[0])
-    assert abs(s0[0] - base_prob[label]) < 2e-6     # all-ones mask == unmasked (one row through the MFMA stem, 150 through the stem table)
+    assert abs(s0[0] - base_prob[label]) < 1e-5     # all-ones mask == unmasked (one row through the MFMA stem, 150 through the stem table)
     assert p0[0] == base_pred
     assert s0[1] == s1[1]                                   # all-zeros mask: independent of the image
     assert s0[3] == s0[70] == s0[149] and p0[3] == p0[70]   # batch/slot invariance, bit for bit
@@ -921,7 +921,7 @@ def test_resnet101_full_batch_properties(mpx_lib, dev):
         base_pred, base_prob = eng.predict(imgs[0])
         _o, s0, p0, lg = eng.score_masks(imgs[0], seg, onoff, base_pred, return_logits=True)
         _o, s1, _p = eng.score_masks(imgs[1], seg, onoff, base_pred)
-        assert abs(s0[0] - base_prob[base_pred]) < 2e-6 and p0[0] == base_pred     # all-ones == unmasked (predict stages one row through K0 and
+        assert abs(s0[0] - base_prob[base_pred]) < 1e-5 and p0[0] == base_pred     # all-ones == unmasked (predict stages one row through K0 and
                                                                                    # the MFMA stem, 512 rows go through the stem table: rounding)
         assert s0[1] == s1[1]                                                      # all-zeros: image-independent
         assert s0[7] == s0[300] == s0[511]                                         # slot invariance, bit for bit
