@@ -376,7 +376,9 @@ def main(argv=None):
                         "traffic": (traffic_per_batch / (conv_n / forwards_profiled)) if traffic_per_batch else None,
                         # NOT measured in this run: PMC counters need rocprofv3; the file holds the per-batch bytes of the same forward
                         "traffic_source": traffic_source, "traffic_bytes_per_forward_batch": traffic_per_batch,
-                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv3x3pp_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel (all conv launches)", "launches": conv_n,
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv3x3pp_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel"
+                                  + (" + stem_apply_kernel (conv1 + bn1 + relu + maxpool of all masks of an image from its superposition table)" if eng.stem == "table" else "")
+                                  + " (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,
                         # f16x3 issues three fp16 MFMA products per algorithmic product: at fp32-equivalent precision the
                         # path's own arithmetic ceiling is peak/3 (the north-star's 0.90 of 2.5 PF is out of reach by construction)
@@ -393,7 +395,8 @@ def main(argv=None):
             "metric": "masked-forward-passes/sec (224x224, %s)" % args.arch,
             "value": value, "unit": "masked-forward-passes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3 (split-fp16 MFMA, fp32 accumulate)" + ("; stem conv in fp32 by superposition over superpixels" if eng.stem == "table" else ""),
             "data": "synthetic (random-init torchvision-shaped weights, uniform-random u8 images, 14x14-block label map)",
             "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
                        "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "num_cus": eng.num_cus,
