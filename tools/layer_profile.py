@@ -67,13 +67,24 @@ if os.environ.get("MPX_TILE_C64"):      # tool-only override: one tile variant o
 if os.environ.get("MPX_TILE_ALL"):      # tool-only override: force one tile variant on every conv
     for i in range(len(eng.layers)):
         eng.set_conv_tile(i, int(os.environ["MPX_TILE_ALL"]))
+table = eng.stem == "table" and not os.environ.get("MPX_STEM_CONV")      # tool-only: MPX_STEM_CONV=1 = K0 + the MFMA stem (rounds 1-3)
+
+
+def stage():
+    if table:               # the engine's default for an image with this many rows: the stem by superposition (row 0 of the table = its apply launch)
+        eng.build_stem_table(img, seg, 196)
+        eng.apply_stem_table(onoff, 0)
+    else:
+        eng.stage_masks(img, seg, onoff, 0)
+
+
 for _ in range(2):
-    eng.stage_masks(img, seg, onoff, 0)
+    stage()
     eng.forward(batch, labels)
 torch.cuda.synchronize()
 eng.profile(True)
 for _ in range(reps):
-    eng.stage_masks(img, seg, onoff, 0)
+    stage()
     eng.forward(batch, labels)
 eng.profile(False)
 prof = eng.collect_profile()
