@@ -185,3 +185,48 @@ def test_table_stem_engine_vs_conv_stem_engine_vs_cpu_loop(mpx_lib, arch, tight)
     finally:
         tab.close()
         conv.close()
+
+
+def test_stem_table_apply_is_deterministic_and_block_independent(mpx_lib, golden_dir):
+    """The apply launch meets its four waves' values in LDS (two buffers, one barrier per four masks) and takes one of four code paths
+    per pooled pixel: the same rows must give the same bits (a) launched again next to a side stream that keeps HBM busy, (b) as one
+    call of 515 rows (17 mask blocks, the last of 3) and as calls of 1, 2, 33 and 479 rows, (c) at another slot offset."""
+    dev = torch.device("cuda", 0)
+    eng = MaskedForwardEngine("resnet18", max_batch=600, device=0).load_state_dict(synth.make_state_dict("resnet18"))
+    try:
+        img = torch.from_numpy(synth.make_images(1, seed=61, kind="blobs")[0]).to(dev)
+        seg_np = _segments("felz", golden_dir)
+        s = int(seg_np.max()) + 1
+        seg = torch.from_numpy(seg_np).to(dev)
+        onoff = torch.from_numpy(synth.random_onoff(515, s, seed=62)).to(dev)
+        eng.build_stem_table(img, seg, s)
+        hi, lo = eng.stem_planes(600)
+
+        def run(parts, slot0):
+            hi.fill_(float("nan"))
+            lo.fill_(float("nan"))
+            at = 0
+            for n in parts:
+                eng.apply_stem_table(onoff[at:at + n].contiguous(), slot0 + at)
+                at += n
+            torch.cuda.synchronize()
+            return hi[slot0:slot0 + 515].clone(), lo[slot0:slot0 + 515].clone()
+
+        want = run([515], 0)
+        assert not torch.isnan(want[0].float()).any()
+        side = torch.cuda.Stream(device=dev)
+        big_a = torch.empty(1 << 27, dtype=torch.float32, device=dev).normal_()
+        big_b = torch.empty_like(big_a)
+        for _ in range(3):
+            with torch.cuda.stream(side):
+                for _c in range(4):
+                    big_b.copy_(big_a)
+            got = run([515], 0)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        torch.cuda.synchronize()
+        got = run([1, 2, 33, 479], 0)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        got = run([515], 85)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    finally:
+        eng.close()
