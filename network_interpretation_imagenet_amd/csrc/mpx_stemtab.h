@@ -218,35 +218,52 @@ __device__ __forceinline__ void stem_entry(const StemRows& w, int i, int& g, boo
 // its entry i and lays the eight masks' factors out in LDS; a conv pixel's end is a branch on the scalar unit (see the asm below).
 constexpr int SA_CH = 32, SA_MG = 8;
 
+__device__ __forceinline__ void stem_load_chunk(const StemApplyParams& p, const StemRows& w, int cb, int n_e, int lane, int mb,
+                                                float (&R)[SA_CH], unsigned& starts, unsigned& kbv) {
+    const int cnt = min(SA_CH, n_e - cb);
+    starts = 0;
+#pragma unroll
+    for (int i = 0; i < SA_CH; ++i) {
+        int g = 0;
+        bool st = false;
+        stem_entry(w, cb + i, g, st);
+        const bool ok = i < cnt;
+        R[i] = ok ? p.vec[(size_t)g * ST_C + lane] : 0.f;
+        if (ok && st && cb + i > 0) starts |= 1u << i;
+    }
+    kbv = 0;                                    // lane i: the keep bits (32 masks) of entry cb + i
+    if (lane < cnt) {
+        int g = 0;
+        bool st = false;
+        stem_entry(w, cb + lane, g, st);
+        kbv = p.bits[(size_t)p.lab[g] * p.nmb + mb];
+    }
+}
+
 __device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float* s_ks, int wave, int lane, int mcount,
                                                   size_t out0_row, const StemRows& w, int n_e, int n_empty, float sc, float sh, int mb) {
     const float y_empty = fmaxf(sh, 0.f);       // a conv pixel none of whose taps lies in a kept superpixel: relu(bn(0))
-    for (int mg = 0; mg < mcount; mg += SA_MG) {
-        float v[SA_MG], best[SA_MG];
+    const int n_ch = (n_e + SA_CH - 1) / SA_CH;             // chunks per pass over the entries (0 for a pixel without entries)
+    const int n_mg = (mcount + SA_MG - 1) / SA_MG;
+    float v[SA_MG], best[SA_MG];
+    // (mask group, chunk) pairs in one sequence: the loads of the NEXT pair's entries are issued before this pair's arithmetic -- a wave on
+    // this path used to wait a table round trip per pair, and the three fast waves of its workgroup waited with it at every store barrier
+    float R[SA_CH], Rn[SA_CH];
+    unsigned starts = 0, kbv = 0, starts_n = 0, kbv_n = 0;
+    if (n_ch > 0) stem_load_chunk(p, w, 0, n_e, lane, mb, R, starts, kbv);
+    for (int mgi = 0; mgi < n_mg; ++mgi) {
+        const int mg = mgi * SA_MG;
 #pragma unroll
         for (int j = 0; j < SA_MG; ++j) {
             v[j] = 0.f;
             best[j] = n_empty > 0 ? y_empty : -INFINITY;
         }
-        for (int cb = 0; cb < n_e; cb += SA_CH) {
+        for (int ci = 0; ci < n_ch; ++ci) {
+            const int cb = ci * SA_CH;
             const int cnt = min(SA_CH, n_e - cb);
-            float R[SA_CH];
-            unsigned starts = 0;
-#pragma unroll
-            for (int i = 0; i < SA_CH; ++i) {
-                int g = 0;
-                bool st = false;
-                stem_entry(w, cb + i, g, st);
-                const bool ok = i < cnt;
-                R[i] = ok ? p.vec[(size_t)g * ST_C + lane] : 0.f;
-                if (ok && st && cb + i > 0) starts |= 1u << i;
-            }
-            unsigned kbv = 0;                   // lane i: the keep bits (32 masks) of entry cb + i
-            if (lane < cnt) {
-                int g = 0;
-                bool st = false;
-                stem_entry(w, cb + lane, g, st);
-                kbv = p.bits[(size_t)p.lab[g] * p.nmb + mb];
+            {   // prefetch: the next chunk of this group, or the first chunk again for the next group
+                const int ci_n = ci + 1 < n_ch ? ci + 1 : 0;
+                if (ci + 1 < n_ch || mgi + 1 < n_mg) stem_load_chunk(p, w, ci_n * SA_CH, n_e, lane, mb, Rn, starts_n, kbv_n);
             }
             // the 0.0 / 1.0 keep factors of the group's eight masks for the chunk's entries, [mask][entry] in the wave's LDS slice; they come
             // back four entries per broadcast ds_read_b128
@@ -279,6 +296,10 @@ __device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsi
                     }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < SA_CH; ++i) R[i] = Rn[i];
+            starts = starts_n;
+            kbv = kbv_n;
         }
 #pragma unroll
         for (int j = 0; j < SA_MG; ++j) {
@@ -297,10 +318,10 @@ __device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsi
 // scalar unit (s_and, s_cmp, s_cselect per slot) made the launch scalar-bound at 3 x the time of its vector instructions.
 constexpr int SA_KF_PITCH = 40;                 // floats per mask row: 36 slots, 16-byte aligned rows
 
-template <int KPP>
+template <int KPP, bool BORDER>
 __device__ __forceinline__ void stem_apply_fast(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float (*s_kf)[SA_KF_PITCH], int wave,
-                                                int lane, int mcount, size_t out0_row, const int (&o)[9], const int (&len)[9], float sc, float sh,
-                                                int mb) {
+                                                int lane, int mcount, size_t out0_row, const int (&o)[9], const int (&len)[9],
+                                                const bool (&qok)[9], float sc, float sh, int mb) {
     constexpr int NS = 9 * KPP, NS4 = (NS + 3) / 4 * 4;
     float R[NS4];
 #pragma unroll
@@ -332,7 +353,9 @@ __device__ __forceinline__ void stem_apply_fast(const StemApplyParams& p, unsign
 #pragma unroll
             for (int k = 0; k < KPP; ++k)       // 1.0 * R + v and 0.0 * R + v are exact for finite R
                 v = fmaf(kf[(q * KPP + k) / 4][(q * KPP + k) % 4], R[q * KPP + k], v);
-            best = fmaxf(best, fmaxf(fmaf(v, sc, sh), 0.f));
+            const float y = fmaxf(fmaf(v, sc, sh), 0.f);
+            // BORDER (first pooled row / column): a conv pixel outside the map takes no part in the pool
+            best = fmaxf(best, BORDER ? (qok[q] ? y : -INFINITY) : y);
         }
         stem_store4(p, s_out, m, mcount, wave, lane, best, out0_row);
     }
@@ -372,22 +395,39 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p
     const int n_e = w.l0 + w.l1 + w.l2;
     const float sc = p.s[lane], sh = p.t[lane];
     const size_t out0_row = (((size_t)(p.slot0 + m0) * ST_POOLED + py) * ST_POOLED + (px - wave)) * ST_C;
-    // the per-pixel view of the same ranges for the fast path
-    const int o9[9] = {w.o00, w.o01, w.o02, w.o10, w.o11, w.o12, w.o20, w.o21, w.o22};
-    const int end9[3] = {w.a0 + w.l0, w.a1 + w.l1, w.a2 + w.l2};
-    int len9[9], kmax = 0;
+    // the per-pixel view for the static paths: conv pixel q = 3 * r + c at row 2py-1+r, column 2px-1+c; pixels outside the map (r = 0 for
+    // py = 0, c = 0 for px = 0) are absent
+    const bool col0_ok = px > 0, row0_ok = py > 0;
+    const int e0[4] = {w.o00, w.o01, w.o02, w.a0 + w.l0}, e1[4] = {w.o10, w.o11, w.o12, w.a1 + w.l1}, e2[4] = {w.o20, w.o21, w.o22, w.a2 + w.l2};
+    int o9[9], len9[9], kmax = 0;
+    bool qok[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        len9[q] = ((q % 3 == 2) ? end9[q / 3] : o9[q + 1]) - o9[q];
-        kmax = max(kmax, len9[q]);
+    for (int c = 0; c < 3; ++c) {
+        // with the left column absent the row's ranges start at column 1: range index = c - 1
+        const int j = col0_ok ? c : c - 1;
+        const bool cok = col0_ok || c > 0;
+        qok[c] = cok && row0_ok;
+        qok[3 + c] = cok;
+        qok[6 + c] = cok;
+        o9[c] = cok ? e0[cok ? j : 0] : 0;
+        o9[3 + c] = cok ? e1[cok ? j : 0] : 0;
+        o9[6 + c] = cok ? e2[cok ? j : 0] : 0;
+        len9[c] = qok[c] ? e0[j + 1] - e0[j] : 0;
+        len9[3 + c] = cok ? e1[j + 1] - e1[j] : 0;
+        len9[6 + c] = cok ? e2[j + 1] - e2[j] : 0;
     }
-    const bool interior = py > 0 && px > 0;             // all nine conv pixels inside the map (ncol = 3, row 0 valid)
-    if (interior && kmax <= 1) {
-        stem_apply_fast<1>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
-    } else if (interior && kmax <= 2) {
-        stem_apply_fast<2>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
-    } else if (interior && kmax <= 4) {
-        stem_apply_fast<4>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, sc, sh, mb);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) kmax = max(kmax, len9[q]);
+    const bool interior = col0_ok && row0_ok;
+    if (kmax <= 4) {
+        if (interior) {
+            if (kmax <= 1) stem_apply_fast<1, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+            else if (kmax <= 2) stem_apply_fast<2, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+            else stem_apply_fast<4, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+        } else {
+            if (kmax <= 2) stem_apply_fast<2, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+            else stem_apply_fast<4, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+        }
     } else {
         stem_apply_stream(p, s_out, &s_kf[wave][0][0], wave, lane, mcount, out0_row, w, n_e, n_empty, sc, sh, mb);
     }
