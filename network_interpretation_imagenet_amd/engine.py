@@ -99,7 +99,7 @@ class MaskedForwardEngine:
         """stem: how score_packed / score_masks / score_images stage the masks of an image on the ImageNet ResNets --
         "table" (default): the stem by superposition (mpx_stem_table_build once per image, mpx_stem_table_apply per block of mask rows:
         K0, the stem conv and its max pool for all masks of an image without materialising a masked image) whenever a call brings at
-        least `stem_table_min_rows` (96) rows per image, K0 + the MFMA stem otherwise (a BO round's 28 .. 118 windows); "conv": always
+        least `stem_table_min_rows` (256) rows per image, K0 + the MFMA stem otherwise (a BO round's 28 .. 118 windows); "conv": always
         K0 into the input staging, then the MFMA stem + max pool inside the forward (rounds 1-3).  stage_masks() is always K0."""
         if arch not in ARCH_IDS:
             raise ValueError("unsupported arch %r (torchvision ResNets and the reference's small networks: %s)" % (arch, sorted(ARCH_IDS)))
@@ -126,9 +126,11 @@ class MaskedForwardEngine:
         _lib.check(h, self._lib.mpx_geometry(h, *[C.byref(v) for v in g]), "mpx_geometry")
         self.image_size, self.in_channels, self.num_classes, self.logit_pitch = (int(v.value) for v in g)
         self.small = self.image_size != IMG
-        # below this many mask rows per image the table does not pay: building it costs what K0 + the MFMA stem cost for ~40 masks, and
-        # a short apply launch leaves the chip half empty (tools/stem_bench.py: 37 rows per image 8.0 against 3.9 ms per 2340 rows)
-        self.stem_table_min_rows = 96
+        # below this many mask rows per image the table does not pay for every label map: building it costs what K0 + the MFMA stem cost
+        # for ~40 masks and a short apply launch leaves the chip half empty.  tools/stem_bench.py, ms per 2340 rows, table / K0 + MFMA
+        # stem: 16-pixel grid 96 rows per image 3.1 / 3.6, 256 rows 1.8 / 3.5, 512 rows 1.4 / 3.5; the (fragmented) felzenszwalb fixture
+        # 128 rows 5.2 / 3.7, 256 rows 3.8 / 3.6, 512 rows 3.0 / 3.6 -- 256 is where no map loses
+        self.stem_table_min_rows = 256
         if stem not in (None, "table", "conv"):
             raise ValueError("stem must be 'table' or 'conv', got %r" % (stem,))
         if self.small and stem == "table":
