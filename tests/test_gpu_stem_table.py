@@ -170,7 +170,7 @@ def test_table_stem_engine_vs_conv_stem_engine_vs_cpu_loop(mpx_lib, arch, tight)
     conv = MaskedForwardEngine(arch, max_batch=24, device=0, stem="conv").load_state_dict(sd)
     try:
         assert tab.stem == "table" and conv.stem == "conv"
-        tab.stem_table_min_rows = 1              # 40 rows: below the default threshold of 96 rows per image
+        tab.stem_table_min_rows = 1              # 40 rows: below the default threshold (256 rows per image)
         label = tab.predict(img)[0]
         assert conv.predict(img)[0] == label
         _o, s_t, p_t = tab.score_masks(img, seg, onoff, label)
