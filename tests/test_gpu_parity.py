@@ -449,7 +449,7 @@ def test_forward_fused_vs_unfused_downsample(eng101):
 
 
 @pytest.mark.parametrize("name,unfused_mask", [("layer1.1.conv3", 1), ("layer1.0.conv3", 1), ("layer1.0.downsample.0", 0),
-                                               ("layer2.0.downsample.0", 0), ("layer3.0.conv3", 0), ("layer1.2.conv2", 1), ("layer2.0.conv1", 1)])
+                                               ("layer3.0.conv3", 0), ("layer2.0.conv1", 1)])
 def test_reloading_one_layer_rebuilds_what_was_derived_from_it(mpx_lib, dev, name, unfused_mask):
     """mpx_set_conv_weights on ONE layer after the engine is complete (mpx_api.hip: the tail's permuted conv3 copy, the
     K-concatenated conv3 | downsample planes and the tail copy of THOSE are derived tensors): the fused forward must follow the
@@ -590,14 +590,14 @@ def _tiles_of(eng, d, batch, tp, tc):
     return -(-batch * d.hout * d.hout // tp) * (d.cout // tc)
 
 
-@pytest.mark.parametrize("batch", [1, 3, 11, 41, 335, 347, 392, 523])
+@pytest.mark.parametrize("batch", [1, 11, 41, 335, 392, 523])
 @pytest.mark.parametrize("name", ["layer2.1.conv2", "layer3.5.conv2", "layer3.22.conv2", "layer4.1.conv2"])
 def test_conv_persistent_patch_kernel(eng101, name, batch):
     """Tile id 12 = the patch kernel as one persistent workgroup per CU (csrc/mpx_conv3pp.h): weight ring and patch buffers run on
     across the tiles of a workgroup, register epilogue, the next tile's geometry computed inside the K loop with float-reciprocal
     divisions.  A launch with fewer tiles than CUs runs on tile 6 itself (launch_conv_patchp: batches 1 .. 41 on 14x14 / 7x7 maps,
     1 .. 11 on 28x28) -- those cases check the fallback rule; the larger batches stay on the persistent walk with UNEVEN tile counts
-    per workgroup: 256 -> 256 on 14x14 maps (two cout tiles) 335 images = 257 x 2 tiles, 347 = 266 x 2, 392 = 301 x 2, 523 = 401 x 2;
+    per workgroup: 256 -> 256 on 14x14 maps (two cout tiles) 335 images = 257 x 2 tiles, 392 = 301 x 2, 523 = 401 x 2;
     128 -> 128 on 28x28 maps 335 images = 1026 tiles; 512 -> 512 on 7x7 maps (192-pixel tiles, four cout tiles) 41 images = 44 and
     335 = 344 tiles.  Every case asserts which kernel ran.  Against the fp64 conv + BN for the small batches, and
     BIT-identical to tile 6 for all of them (mpx_conv_bn_act takes any batch: the planes are the caller's)."""
@@ -626,7 +626,7 @@ def test_conv_persistent_patch_kernel(eng101, name, batch):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("batch", [1, 11, 41, 335, 347, 523, 700, 1013])
+@pytest.mark.parametrize("batch", [1, 41, 335, 523, 700, 1013])
 @pytest.mark.parametrize("name", ["layer2.1.conv1", "layer3.5.conv1", "layer4.1.conv1"])
 def test_conv_persistent_256_kernel(eng101, name, batch):
     """Tile id 13 = the 256x256 kernel as one persistent workgroup per CU (csrc/mpx_conv256p.h): the two-stage ring runs on across
@@ -634,7 +634,7 @@ def test_conv_persistent_256_kernel(eng101, name, batch):
     tile's first step (vmcnt(32) at its rendezvous).  512 -> 128 is not eligible (cout % 256).  A launch with fewer tiles than CUs
     runs on the 128x128 kernel, which sums in the same order (launch_conv256p); from one round on the persistent walk runs, and when
     a small last round is left (launch_conv: rest <= half the CUs) the images behind the whole rounds go to the 128x128 kernel too:
-    1024 -> 256 on 14x14 at 335 / 347 / 700 images = 257 / 266 / 536 tiles -> the whole rounds persistent + the rest on tile 2; 523
+    1024 -> 256 on 14x14 at 335 / 700 images = 257 / 536 tiles -> the whole rounds persistent + the rest on tile 2; 523
     images = 401 tiles (rest 145 > half the CUs) -> all on the persistent walk with uneven tile counts per workgroup; 2048 -> 512 on
     7x7 (two cout tiles) at 700 images = 268 tiles (split) and 1013 = 388 (all persistent).  Every case asserts which kernels ran.  Against the fp64 conv + BN for the small batches, BIT-identical to tile 9 for all."""
     sd = synth.make_state_dict("resnet101")
