@@ -312,11 +312,12 @@ __device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsi
 }
 
 // Fast path: a pooled pixel away from the top / left border (all 3 x 3 conv pixels valid) whose conv pixels have at most KPP entries each
-// (KPP = 1, 2, 4: the window of a conv pixel inside one superpixel, across one boundary, at a corner of a grid).  Slot (q, k) = entry k of
+// (KPP = 1, 2, 3, 4, 6: the window of a conv pixel inside one superpixel, across one boundary, at a junction, at a corner of a grid, in a
+// fragmented part of a felzenszwalb map).  Slot (q, k) = entry k of
 // conv pixel q, or a zero: fully static code, one fma per slot, one fma + max3 per conv pixel.  The 0.0 / 1.0 keep factors of the 32 masks
 // are laid out once per wave in LDS ([mask][slot]) and come back four slots per broadcast ds_read_b128: extracting them per mask on the
 // scalar unit (s_and, s_cmp, s_cselect per slot) made the launch scalar-bound at 3 x the time of its vector instructions.
-constexpr int SA_KF_PITCH = 40;                 // floats per mask row: 36 slots, 16-byte aligned rows
+constexpr int SA_KF_PITCH = 56;                 // floats per mask row: up to 54 slots (KPP = 6), 16-byte aligned rows
 
 template <int KPP, bool BORDER>
 __device__ __forceinline__ void stem_apply_fast(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float (*s_kf)[SA_KF_PITCH], int wave,
@@ -419,10 +420,13 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p
 #pragma unroll
     for (int q = 0; q < 9; ++q) kmax = max(kmax, len9[q]);
     const bool interior = col0_ok && row0_ok;
-    if (kmax <= 4) {
-        if (interior) {
+    if (kmax <= 6 && (kmax <= 4 || interior)) {
+        if (interior && kmax > 4) {
+            stem_apply_fast<6, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+        } else if (interior) {
             if (kmax <= 1) stem_apply_fast<1, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
             else if (kmax <= 2) stem_apply_fast<2, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+            else if (kmax <= 3) stem_apply_fast<3, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
             else stem_apply_fast<4, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
         } else {
             if (kmax <= 2) stem_apply_fast<2, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
