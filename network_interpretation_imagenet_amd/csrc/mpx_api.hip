@@ -133,6 +133,7 @@ struct mpx_engine {
     int* tab_cnt = nullptr;
     int* tab_off = nullptr;
     int* tab_lab = nullptr;
+    int* tab_heavy = nullptr;       // [56 * 56 + 1]: the heavy pooled pixels of the table in place, last element = their number
     float* tab_vec = nullptr;
     unsigned* tab_bits = nullptr;   // [4096][ceil(max_batch / 32) + 1]
     int tab_S = -1;                 // S of the table in place (-1: none)
@@ -1155,7 +1156,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     const size_t tab_lab_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * 4, 256) : 0;
     const size_t tab_vec_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * ST_C * 4, 256) : 0;
     const size_t tab_bits_bytes = stemtab ? round_up((size_t)4096 * tab_nmb * 4, 256) : 0;
-    const size_t stemtab_bytes = 2 * stem_plane + stem_w_bytes + 2 * tab_int_bytes + tab_lab_bytes + tab_vec_bytes + tab_bits_bytes;
+    const size_t stemtab_bytes = 2 * stem_plane + stem_w_bytes + 3 * tab_int_bytes + tab_lab_bytes + tab_vec_bytes + tab_bits_bytes;
     const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes + stemtab_bytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
@@ -1181,6 +1182,7 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         h->stem_t32 = (float*)take(256);
         h->tab_cnt = (int*)take(tab_int_bytes);
         h->tab_off = (int*)take(tab_int_bytes);
+        h->tab_heavy = (int*)take(tab_int_bytes);
         h->tab_lab = (int*)take(tab_lab_bytes);
         h->tab_vec = (float*)take(tab_vec_bytes);
         h->tab_bits = (unsigned*)take(tab_bits_bytes);
@@ -1451,6 +1453,8 @@ int mpx_stem_table_build(mpx_engine* h, const uint8_t* img_u8_hwc, const float* 
     MPX_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(stemtab_fill_kernel, dim3(ST_NPIX / 4), dim3(256), 0, st, p);
     MPX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(stemtab_heavy_kernel, dim3(1), dim3(1024), 0, st, (const int*)h->tab_off, h->tab_heavy, h->tab_heavy + ST_POOLED * ST_POOLED);
+    MPX_HIP(h, hipGetLastError());
     h->tab_S = S;
     return 0;
 }
@@ -1474,8 +1478,12 @@ int mpx_stem_table_apply(mpx_engine* h, const uint8_t* onoff, int M, int S, int 
     std::memset(&p, 0, sizeof p);
     p.off = h->tab_off; p.lab = h->tab_lab; p.vec = h->tab_vec; p.bits = h->tab_bits; p.s = h->stem_s32; p.t = h->stem_t32;
     p.out_hi = h->stem_hi; p.out_lo = h->stem_lo; p.nmb = nmb; p.M = M; p.slot0 = slot0;
+    p.heavy_list = h->tab_heavy; p.heavy_count = h->tab_heavy + ST_POOLED * ST_POOLED;
     {
         ProfScope ps(h, st, OP_CONV, 0);        // the stem's work: booked on layer 0 like the stem + pool launch it replaces
+        // the pooled pixels with many superpixels under one window first (their workgroups share a pixel's masks), then every pixel
+        hipLaunchKernelGGL(stem_apply_heavy_kernel, dim3(h->num_cus, nmb), dim3(256), 0, st, p);
+        MPX_HIP(h, hipGetLastError());
         hipLaunchKernelGGL(stem_apply_kernel, dim3(ST_POOLED * ST_POOLED / 4, nmb), dim3(256), 0, st, p);
         MPX_HIP(h, hipGetLastError());
     }

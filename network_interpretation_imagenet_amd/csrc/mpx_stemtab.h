@@ -160,6 +160,8 @@ struct StemApplyParams {
     const float* __restrict__ t;          // BatchNorm shift beta - mean * scale, [64]
     half_t* __restrict__ out_hi;          // pooled planes [max_batch][56][56][64]
     half_t* __restrict__ out_lo;
+    const int* __restrict__ heavy_list;   // pooled pixels of the table in place that take the streaming path, and how many
+    const int* __restrict__ heavy_count;
     int nmb, M, slot0;
 };
 
@@ -168,11 +170,9 @@ struct StemApplyParams {
 // two-byte-per-lane stores per forward batch, which the texture addresser serialises: 3.1 ms for the launch, as long as the MFMA stem.)
 // One barrier per four masks, two buffers: a buffer is rewritten two groups later, and the barrier in between needs every wave to have
 // read it.  Every wave of the workgroup calls this once per mask, in order.
-__device__ __forceinline__ void stem_store4(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int m, int mcount, int wave, int lane,
-                                            float best, size_t out0_row) {
-    half_t hi, lo;
-    split_f32(best, hi, lo);
-    s_out[(m >> 2) & 1][m & 3][wave][lane] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+__device__ __forceinline__ void stem_store4_packed(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int m, int mcount, int wave, int lane,
+                                                   unsigned packed, size_t out0_row) {
+    s_out[(m >> 2) & 1][m & 3][wave][lane] = packed;
     if ((m & 3) != 3 && m != mcount - 1) return;
     __syncthreads();
     const int ms = (m & ~3) + wave;             // the mask this wave writes
@@ -189,6 +189,14 @@ __device__ __forceinline__ void stem_store4(const StemApplyParams& p, unsigned (
         __builtin_nontemporal_store(vh, (u2*)(p.out_hi + o));
         __builtin_nontemporal_store(vl, (u2*)(p.out_lo + o));
     }
+}
+
+__device__ __forceinline__ void stem_store4(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], int m, int mcount, int wave, int lane,
+                                            float best, size_t out0_row) {
+    half_t hi, lo;
+    split_f32(best, hi, lo);
+    stem_store4_packed(p, s_out, m, mcount, wave, lane,
+                       (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16), out0_row);
 }
 
 // One wave = one pooled pixel x one block of 32 masks; lane = channel.  The entries of the (up to) 3 x 3 conv pixels under the pooled
@@ -237,77 +245,6 @@ __device__ __forceinline__ void stem_load_chunk(const StemApplyParams& p, const 
         bool st = false;
         stem_entry(w, cb + lane, g, st);
         kbv = p.bits[(size_t)p.lab[g] * p.nmb + mb];
-    }
-}
-
-__device__ __forceinline__ void stem_apply_stream(const StemApplyParams& p, unsigned (*s_out)[4][4][ST_C], float* s_ks, int wave, int lane, int mcount,
-                                                  size_t out0_row, const StemRows& w, int n_e, int n_empty, float sc, float sh, int mb) {
-    const float y_empty = fmaxf(sh, 0.f);       // a conv pixel none of whose taps lies in a kept superpixel: relu(bn(0))
-    const int n_ch = (n_e + SA_CH - 1) / SA_CH;             // chunks per pass over the entries (0 for a pixel without entries)
-    const int n_mg = (mcount + SA_MG - 1) / SA_MG;
-    float v[SA_MG], best[SA_MG];
-    // (mask group, chunk) pairs in one sequence: the loads of the NEXT pair's entries are issued before this pair's arithmetic -- a wave on
-    // this path used to wait a table round trip per pair, and the three fast waves of its workgroup waited with it at every store barrier
-    float R[SA_CH], Rn[SA_CH];
-    unsigned starts = 0, kbv = 0, starts_n = 0, kbv_n = 0;
-    if (n_ch > 0) stem_load_chunk(p, w, 0, n_e, lane, mb, R, starts, kbv);
-    for (int mgi = 0; mgi < n_mg; ++mgi) {
-        const int mg = mgi * SA_MG;
-#pragma unroll
-        for (int j = 0; j < SA_MG; ++j) {
-            v[j] = 0.f;
-            best[j] = n_empty > 0 ? y_empty : -INFINITY;
-        }
-        for (int ci = 0; ci < n_ch; ++ci) {
-            const int cb = ci * SA_CH;
-            const int cnt = min(SA_CH, n_e - cb);
-            {   // prefetch: the next chunk of this group, or the first chunk again for the next group
-                const int ci_n = ci + 1 < n_ch ? ci + 1 : 0;
-                if (ci + 1 < n_ch || mgi + 1 < n_mg) stem_load_chunk(p, w, ci_n * SA_CH, n_e, lane, mb, Rn, starts_n, kbv_n);
-            }
-            // the 0.0 / 1.0 keep factors of the group's eight masks for the chunk's entries, [mask][entry] in the wave's LDS slice; they come
-            // back four entries per broadcast ds_read_b128
-            __builtin_amdgcn_wave_barrier();    // the previous chunk's reads are done
-            if (lane < SA_CH) {
-#pragma unroll
-                for (int j = 0; j < SA_MG; ++j) s_ks[j * SA_CH + lane] = (kbv >> (mg + j) & 1u) ? 1.0f : 0.0f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int j = 0; j < SA_MG; ++j) {
-#pragma unroll
-                for (int i4 = 0; i4 < SA_CH / 4; ++i4) {
-                    const f4 kf = *(const f4*)&s_ks[j * SA_CH + 4 * i4];
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = 4 * i4 + ii;
-                        if (i < cnt) {          // wave-uniform
-                            if (starts >> i & 1) {
-                                // (the empty asm keeps this a BRANCH on the scalar unit: if-converted, every entry would pay the fma + max3
-                                // of a conv pixel's end and two selects -- six vector instructions per entry instead of two)
-                                asm volatile("" ::: "memory");
-                                best[j] = fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f));
-                                v[j] = 0.f;
-                            }
-                            v[j] = fmaf(kf[ii], R[i], v[j]);       // 1.0 * R + v and 0.0 * R + v are exact for finite R
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < SA_CH; ++i) R[i] = Rn[i];
-            starts = starts_n;
-            kbv = kbv_n;
-        }
-#pragma unroll
-        for (int j = 0; j < SA_MG; ++j) {
-            if (mg + j < mcount) {              // every wave of the workgroup stores every mask once: the barrier inside counts on it
-                const float b = n_e > 0 ? fmaxf(best[j], fmaxf(fmaf(v[j], sc, sh), 0.f)) : best[j];
-                stem_store4(p, s_out, mg + j, mcount, wave, lane, b, out0_row);
-            }
-        }
     }
 }
 
@@ -362,21 +299,21 @@ __device__ __forceinline__ void stem_apply_fast(const StemApplyParams& p, unsign
     }
 }
 
-__global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned s_out[2][4][4][ST_C];
-    __shared__ __attribute__((aligned(16))) float s_kf[4][32][SA_KF_PITCH];         // per wave: [mask][slot] keep factors of the fast path
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int P = blockIdx.x * 4 + wave;                        // pooled pixel (3136 = 784 * 4): the workgroup's four are neighbours in a row
-    const int mb = blockIdx.y;
-    const int m0 = mb * 32;
-    const int mcount = min(32, p.M - m0);
-    const int py = P / ST_POOLED, px = P - py * ST_POOLED;
+// The geometry of one pooled pixel: its three CSR row ranges, the per-conv-pixel view for the static paths, the largest entry count.
+struct StemPixel {
+    StemRows w;
+    int n_e, n_empty, kmax;
+    int o9[9], len9[9];
+    bool qok[9];
+    bool interior;
+};
+
+__device__ __forceinline__ void stem_pixel(const StemApplyParams& p, int py, int px, StemPixel& g) {
     // valid conv columns under the pooled pixel (3x3 window, stride 2, pad 1): 2px-1 .. 2px+1 clipped on the left (2 * 55 + 1 = 111 fits)
     const int cx0 = max(2 * px - 1, 0);
     const int ncol = 2 * px + 1 - cx0 + 1;                      // 2 or 3
-    StemRows w;
-    int n_empty = 0;
+    StemRows& w = g.w;
+    g.n_empty = 0;
     {
         // row r = conv row 2py - 1 + r; rows outside the map (r = 0 for py = 0) are empty
         const int cy0 = 2 * py - 1, cy1 = 2 * py, cy2 = 2 * py + 1;
@@ -389,51 +326,164 @@ __global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p
         w.a0 = e00; w.l0 = ok0 ? e03 - e00 : 0; w.o00 = e00; w.o01 = e01; w.o02 = e02;
         w.a1 = e10; w.l1 = e13 - e10; w.o10 = e10; w.o11 = e11; w.o12 = e12;
         w.a2 = e20; w.l2 = e23 - e20; w.o20 = e20; w.o21 = e21; w.o22 = e22;
-        if (ok0) n_empty += (e01 == e00) + (e02 == e01) + (ncol == 3 && e03 == e02);
-        n_empty += (e11 == e10) + (e12 == e11) + (ncol == 3 && e13 == e12);
-        n_empty += (e21 == e20) + (e22 == e21) + (ncol == 3 && e23 == e22);
+        if (ok0) g.n_empty += (e01 == e00) + (e02 == e01) + (ncol == 3 && e03 == e02);
+        g.n_empty += (e11 == e10) + (e12 == e11) + (ncol == 3 && e13 == e12);
+        g.n_empty += (e21 == e20) + (e22 == e21) + (ncol == 3 && e23 == e22);
     }
-    const int n_e = w.l0 + w.l1 + w.l2;
-    const float sc = p.s[lane], sh = p.t[lane];
-    const size_t out0_row = (((size_t)(p.slot0 + m0) * ST_POOLED + py) * ST_POOLED + (px - wave)) * ST_C;
+    g.n_e = w.l0 + w.l1 + w.l2;
     // the per-pixel view for the static paths: conv pixel q = 3 * r + c at row 2py-1+r, column 2px-1+c; pixels outside the map (r = 0 for
     // py = 0, c = 0 for px = 0) are absent
     const bool col0_ok = px > 0, row0_ok = py > 0;
     const int e0[4] = {w.o00, w.o01, w.o02, w.a0 + w.l0}, e1[4] = {w.o10, w.o11, w.o12, w.a1 + w.l1}, e2[4] = {w.o20, w.o21, w.o22, w.a2 + w.l2};
-    int o9[9], len9[9], kmax = 0;
-    bool qok[9];
+    g.kmax = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        // with the left column absent the row's ranges start at column 1: range index = c - 1
-        const int j = col0_ok ? c : c - 1;
         const bool cok = col0_ok || c > 0;
-        qok[c] = cok && row0_ok;
-        qok[3 + c] = cok;
-        qok[6 + c] = cok;
-        o9[c] = cok ? e0[cok ? j : 0] : 0;
-        o9[3 + c] = cok ? e1[cok ? j : 0] : 0;
-        o9[6 + c] = cok ? e2[cok ? j : 0] : 0;
-        len9[c] = qok[c] ? e0[j + 1] - e0[j] : 0;
-        len9[3 + c] = cok ? e1[j + 1] - e1[j] : 0;
-        len9[6 + c] = cok ? e2[j + 1] - e2[j] : 0;
+        const int j = cok ? (col0_ok ? c : c - 1) : 0;          // with the left column absent the row's ranges start at column 1
+        g.qok[c] = cok && row0_ok;
+        g.qok[3 + c] = cok;
+        g.qok[6 + c] = cok;
+        g.o9[c] = e0[j];
+        g.o9[3 + c] = e1[j];
+        g.o9[6 + c] = e2[j];
+        g.len9[c] = g.qok[c] ? e0[j + 1] - e0[j] : 0;
+        g.len9[3 + c] = cok ? e1[j + 1] - e1[j] : 0;
+        g.len9[6 + c] = cok ? e2[j + 1] - e2[j] : 0;
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) kmax = max(kmax, len9[q]);
-    const bool interior = col0_ok && row0_ok;
-    if (kmax <= 6 && (kmax <= 4 || interior)) {
-        if (interior && kmax > 4) {
-            stem_apply_fast<6, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-        } else if (interior) {
-            if (kmax <= 1) stem_apply_fast<1, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-            else if (kmax <= 2) stem_apply_fast<2, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-            else if (kmax <= 3) stem_apply_fast<3, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-            else stem_apply_fast<4, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-        } else {
-            if (kmax <= 2) stem_apply_fast<2, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
-            else stem_apply_fast<4, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, o9, len9, qok, sc, sh, mb);
+    for (int q = 0; q < 9; ++q) g.kmax = max(g.kmax, g.len9[q]);
+    g.interior = col0_ok && row0_ok;
+}
+
+// a pooled pixel the static paths do not take: more than six (border pixels: four) entries under one conv pixel
+__device__ __forceinline__ bool stem_heavy(const StemPixel& g) { return !(g.kmax <= 6 && (g.kmax <= 4 || g.interior)); }
+
+// The list of heavy pooled pixels of the table in place (built once per image, behind the scan: one workgroup, LDS counter).
+__global__ __launch_bounds__(1024) void stemtab_heavy_kernel(const int* __restrict__ off, int* __restrict__ heavy_list, int* __restrict__ heavy_count) {
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    StemApplyParams p;
+    p.off = off;
+    for (int P = threadIdx.x; P < ST_POOLED * ST_POOLED; P += 1024) {
+        StemPixel g;
+        stem_pixel(p, P / ST_POOLED, P % ST_POOLED, g);
+        if (stem_heavy(g)) heavy_list[atomicAdd(&s_n, 1)] = P;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *heavy_count = s_n;
+}
+
+// First launch: the HEAVY pooled pixels only (a fixed grid walks the table's list of them; none = every workgroup returns at once).  The four waves
+// share the pixel's 32 masks, eight each, on the streaming path, and write their 128 bytes per plane and mask themselves -- few pixels, so
+// the narrow stores do not matter.  The second launch copies these values into its four-pixel stores.  (One launch, with the heavy pixel's
+// wave streaming all 32 masks while the three static waves of its workgroup waited at every store barrier, took 2.6 ms on the felzenszwalb
+// fixture against 1.1 on a grid: 11 % of its pixels are heavy, in 38 % of the workgroups.)
+__global__ __launch_bounds__(256) void stem_apply_heavy_kernel(const StemApplyParams p) {
+    __shared__ __attribute__((aligned(16))) float s_ks[4][SA_MG * SA_CH];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mb = blockIdx.y;
+    const int mw0 = wave * SA_MG;                               // this wave's first mask within the block
+    const int mcount = min(SA_MG, p.M - (mb * 32 + mw0));
+    if (mcount <= 0) return;
+    const float sc = p.s[lane], sh = p.t[lane];
+    const float y_empty = fmaxf(sh, 0.f);
+    const int n_heavy = *p.heavy_count;
+    float* ks = s_ks[wave];
+  for (int hi_ = blockIdx.x; hi_ < n_heavy; hi_ += gridDim.x) {
+    const int P = p.heavy_list[hi_];
+    const int py = P / ST_POOLED, px = P - py * ST_POOLED;
+    StemPixel g;
+    stem_pixel(p, py, px, g);
+    float v[SA_MG], best[SA_MG];
+#pragma unroll
+    for (int k = 0; k < SA_MG; ++k) {
+        v[k] = 0.f;
+        best[k] = g.n_empty > 0 ? y_empty : -INFINITY;
+    }
+    for (int cb = 0; cb < g.n_e; cb += SA_CH) {
+        const int cnt = min(SA_CH, g.n_e - cb);
+        float R[SA_CH];
+        unsigned starts = 0, kbv = 0;
+        stem_load_chunk(p, g.w, cb, g.n_e, lane, mb, R, starts, kbv);
+        __builtin_amdgcn_wave_barrier();        // the previous chunk's reads are done
+        if (lane < SA_CH) {
+#pragma unroll
+            for (int k = 0; k < SA_MG; ++k) ks[k * SA_CH + lane] = (kbv >> (mw0 + k) & 1u) ? 1.0f : 0.0f;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < SA_MG; ++k) {
+#pragma unroll
+            for (int i4 = 0; i4 < SA_CH / 4; ++i4) {
+                const f4 kf = *(const f4*)&ks[k * SA_CH + 4 * i4];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = 4 * i4 + ii;
+                    if (i < cnt) {              // wave-uniform
+                        if (starts >> i & 1) {
+                            // (the empty asm keeps this a BRANCH on the scalar unit: if-converted, every entry would pay the fma + max3 of a
+                            // conv pixel's end and two selects -- six vector instructions per entry instead of two)
+                            asm volatile("" ::: "memory");
+                            best[k] = fmaxf(best[k], fmaxf(fmaf(v[k], sc, sh), 0.f));
+                            v[k] = 0.f;
+                        }
+                        v[k] = fmaf(kf[ii], R[i], v[k]);       // 1.0 * R + v and 0.0 * R + v are exact for finite R
+                    }
+                }
+            }
+        }
+    }
+    const size_t out0 = (((size_t)(p.slot0 + mb * 32 + mw0) * ST_POOLED + py) * ST_POOLED + px) * ST_C + lane;
+#pragma unroll
+    for (int k = 0; k < SA_MG; ++k) {
+        if (k < mcount) {
+            const float b = g.n_e > 0 ? fmaxf(best[k], fmaxf(fmaf(v[k], sc, sh), 0.f)) : best[k];
+            half_t hi, lo;
+            split_f32(b, hi, lo);
+            const size_t o = out0 + (size_t)k * ST_POOLED * ST_POOLED * ST_C;
+            p.out_hi[o] = hi;
+            p.out_lo[o] = lo;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();            // the next pixel's first chunk overwrites this wave's factors
+  }
+}
+
+// Second launch: every pooled pixel; a heavy one's wave reads back what the first launch wrote.
+__global__ __launch_bounds__(256) void stem_apply_kernel(const StemApplyParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned s_out[2][4][4][ST_C];
+    __shared__ __attribute__((aligned(16))) float s_kf[4][32][SA_KF_PITCH];         // per wave: [mask][slot] keep factors of the static paths
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = blockIdx.x * 4 + wave;                        // pooled pixel (3136 = 784 * 4): the workgroup's four are neighbours in a row
+    const int mb = blockIdx.y;
+    const int m0 = mb * 32;
+    const int mcount = min(32, p.M - m0);
+    const int py = P / ST_POOLED, px = P - py * ST_POOLED;
+    StemPixel g;
+    stem_pixel(p, py, px, g);
+    const float sc = p.s[lane], sh = p.t[lane];
+    const size_t out0_row = (((size_t)(p.slot0 + m0) * ST_POOLED + py) * ST_POOLED + (px - wave)) * ST_C;
+    if (stem_heavy(g)) {
+        const size_t o0 = out0_row + (size_t)wave * ST_C + lane;
+        for (int m = 0; m < mcount; ++m) {
+            const size_t o = o0 + (size_t)m * ST_POOLED * ST_POOLED * ST_C;
+            const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, p.out_hi[o]) | ((unsigned)__builtin_bit_cast(unsigned short, p.out_lo[o]) << 16);
+            stem_store4_packed(p, s_out, m, mcount, wave, lane, packed, out0_row);
+        }
+    } else if (g.interior) {
+        if (g.kmax <= 1) stem_apply_fast<1, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
+        else if (g.kmax <= 2) stem_apply_fast<2, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
+        else if (g.kmax <= 3) stem_apply_fast<3, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
+        else if (g.kmax <= 4) stem_apply_fast<4, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
+        else stem_apply_fast<6, false>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
     } else {
-        stem_apply_stream(p, s_out, &s_kf[wave][0][0], wave, lane, mcount, out0_row, w, n_e, n_empty, sc, sh, mb);
+        if (g.kmax <= 2) stem_apply_fast<2, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
+        else stem_apply_fast<4, true>(p, s_out, s_kf[wave], wave, lane, mcount, out0_row, g.o9, g.len9, g.qok, sc, sh, mb);
     }
 }
 

@@ -128,8 +128,8 @@ class MaskedForwardEngine:
         self.small = self.image_size != IMG
         # below this many mask rows per image the table does not pay for every label map: building it costs what K0 + the MFMA stem cost
         # for ~40 masks and a short apply launch leaves the chip half empty.  tools/stem_bench.py, ms per 2340 rows, table / K0 + MFMA
-        # stem: 16-pixel grid 96 rows per image 3.1 / 3.6, 256 rows 1.8 / 3.5, 512 rows 1.4 / 3.5; the (fragmented) felzenszwalb fixture
-        # 128 rows 5.2 / 3.7, 256 rows 3.8 / 3.6, 512 rows 3.0 / 3.6 -- 256 is where no map loses
+        # stem: 16-pixel grid 96 rows per image 3.2 / 3.6, 256 rows 1.9 / 3.5, 512 rows 1.5 / 3.5; the (fragmented) felzenszwalb fixture
+        # 96 rows 5.5 / 3.7, 256 rows 3.1 / 3.5, 512 rows 2.3 / 3.6 -- at 256 no map loses
         self.stem_table_min_rows = 256
         if stem not in (None, "table", "conv"):
             raise ValueError("stem must be 'table' or 'conv', got %r" % (stem,))
