@@ -6,7 +6,8 @@
 //     R[q][s] = sum over the taps of that window that lie in superpixel s of  w[tap] * x[tap]          (mask-independent)
 // A window touches 1 .. 4 superpixels on a 16-pixel grid (1.9 on average) and a handful on felzenszwalb maps.  So per IMAGE the
 // table R is built once (one fp32 conv of the image, its taps bucketed by label: stemtab_*_kernel), and per MASK the stem is a gather:
-// y = relu(bn(sum of the kept entries)), 3x3 stride-2 max pool, split into the hi + lo planes (stem_apply_kernel) -- no MFMA, no
+// y = relu(bn(sum of the kept entries)), 3x3 stride-2 max pool, split into the hi + lo planes (stem_apply_heavy_kernel for the few pooled
+// pixels with many superpixels under one window, then stem_apply_kernel for all) -- no MFMA, no
 // staged input: K0's 846 KB per masked image are neither written nor read, and the 118 MMAC of the stem conv per mask become ~20 adds
 // per pooled pixel and channel.  Arithmetic: the table entries are fp32 FMA chains over the taps in raster order (the reference's own
 // arithmetic type), the mask sum adds them in the order of first occurrence of their label in the window; the result differs from the
@@ -219,11 +220,12 @@ __device__ __forceinline__ void stem_entry(const StemRows& w, int i, int& g, boo
     }
 }
 
-// General path (border pixels, conv pixels with more than four entries, any label map): the entries are streamed through registers 32 at
-// a time and EIGHT masks are carried at once -- per mask the running sum of the open conv pixel and the running pool maximum -- so a
-// pooled pixel with any number of entries runs at register speed (an earlier version re-read the table per mask for the long ones: three
-// dependent loads per entry, and the few waves that took that path set the launch's duration).  Lane i of a chunk holds the keep bits of
-// its entry i and lays the eight masks' factors out in LDS; a conv pixel's end is a branch on the scalar unit (see the asm below).
+// Streaming path (the heavy pixels: more than six entries under one conv pixel, any label map; stem_apply_heavy_kernel): the entries are
+// streamed through registers 32 at a time and a wave's EIGHT masks are carried at once -- per mask the running sum of the open conv pixel
+// and the running pool maximum -- so a pooled pixel with any number of entries runs at register speed (an earlier version re-read the table
+// per mask for the long ones: three dependent loads per entry, and the few waves that took that path set the launch's duration).  Lane i of
+// a chunk holds the keep bits of its entry i and lays the eight masks' factors out in LDS; a conv pixel's end is a branch on the scalar
+// unit (see the asm there).
 constexpr int SA_CH = 32, SA_MG = 8;
 
 __device__ __forceinline__ void stem_load_chunk(const StemApplyParams& p, const StemRows& w, int cb, int n_e, int lane, int mb,
@@ -248,7 +250,8 @@ __device__ __forceinline__ void stem_load_chunk(const StemApplyParams& p, const 
     }
 }
 
-// Fast path: a pooled pixel away from the top / left border (all 3 x 3 conv pixels valid) whose conv pixels have at most KPP entries each
+// Static paths: a pooled pixel whose conv pixels have at most KPP entries each (BORDER: first pooled row / column, where conv pixels
+// outside the map take no part in the pool)
 // (KPP = 1, 2, 3, 4, 6: the window of a conv pixel inside one superpixel, across one boundary, at a junction, at a corner of a grid, in a
 // fragmented part of a felzenszwalb map).  Slot (q, k) = entry k of
 // conv pixel q, or a zero: fully static code, one fma per slot, one fma + max3 per conv pixel.  The 0.0 / 1.0 keep factors of the 32 masks
