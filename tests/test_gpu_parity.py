@@ -135,7 +135,8 @@ def _conv_reference(sd, d, x_nchw64, res_nchw64):
     return F.relu(y) if d.relu else y
 
 
-def _run_conv(eng, i, x_nhwc, res_nhwc, batch):
+def _run_conv(eng, i, x_nhwc, res_nhwc, batch, on_device=False):
+    """on_device: return only the merged output, left on the GPU (kernel-against-kernel comparisons of large batches)"""
     d = eng.layers[i]
     dev = eng.device
     xh, xl = split(x_nhwc.to(dev))
@@ -147,6 +148,8 @@ def _run_conv(eng, i, x_nhwc, res_nhwc, batch):
     rc = eng._lib.mpx_conv_bn_act(eng._h, i, _p(xh), _p(xl), _p(rh), _p(rl), _p(oh), _p(ol), None, batch, eng._stream())
     _lib.check(eng._h, rc, "mpx_conv_bn_act")
     torch.cuda.synchronize()
+    if on_device:
+        return (merge(oh, ol),)
     return merge(oh, ol).cpu(), merge(xh, xl).cpu(), (merge(rh, rl).cpu() if rh is not None else None)
 
 
@@ -608,12 +611,13 @@ def test_conv_persistent_patch_kernel(eng101, name, batch):
     d = eng101.layers[i]
     if d.hout == 28 and batch > 347:
         pytest.skip("28x28 maps: 347 images are 1063 tiles already")
-    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(7)).clamp_min(-0.5)
+    # (drawn on the device: the two kernels are compared with each other, and 523 images of a CPU randn cost more than the launches)
+    x = torch.randn(batch, d.hin, d.hin, d.cin, device=eng101.device, generator=torch.Generator(device=eng101.device).manual_seed(7)).clamp_min(-0.5)
     outs, ran = [], []
     for tile in (6, 12):
         eng101.set_conv_tile(i, tile)
         try:
-            outs.append(_run_conv(eng101, i, x, None, batch)[0])
+            outs.append(_run_conv(eng101, i, x, None, batch, on_device=True)[0])
             ran.append(_kernels_ran(eng101))
         finally:
             eng101.set_conv_tile(i, -1)
@@ -645,12 +649,12 @@ def test_conv_persistent_256_kernel(eng101, name, batch):
         return
     if batch <= 11:
         _check_layer(eng101, sd, name, batch=batch, tile=13)
-    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=torch.Generator().manual_seed(11)).clamp_min(-0.5)
+    x = torch.randn(batch, d.hin, d.hin, d.cin, device=eng101.device, generator=torch.Generator(device=eng101.device).manual_seed(11)).clamp_min(-0.5)
     outs, ran = [], []
     for tile in (9, 13):
         eng101.set_conv_tile(i, tile)
         try:
-            outs.append(_run_conv(eng101, i, x, None, batch)[0])
+            outs.append(_run_conv(eng101, i, x, None, batch, on_device=True)[0])
             ran.append(_kernels_ran(eng101))
         finally:
             eng101.set_conv_tile(i, -1)
