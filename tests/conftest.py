@@ -24,3 +24,21 @@ def mpx_lib():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cached_synthetic_state_dicts():
+    """synth.make_state_dict(arch) draws 44 M ResNet-101 weights in ~2 s and a hundred tests ask for the same dict: hand out one set of
+    tensors per (arch, seed) in a fresh OrderedDict (the tests treat the tensors as read-only; they copy before they change one)."""
+    from network_interpretation_imagenet_amd import synth
+    real, cache = synth.make_state_dict, {}
+
+    def cached(arch, seed=7):
+        key = (arch, seed)
+        if key not in cache:
+            cache[key] = real(arch, seed)
+        return type(cache[key])(cache[key])
+
+    synth.make_state_dict = cached
+    yield
+    synth.make_state_dict = real
