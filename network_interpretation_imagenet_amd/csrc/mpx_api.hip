@@ -7,6 +7,7 @@
 #include "mpx_conv256.h"
 #include "mpx_conv256p.h"
 #include "mpx_convx.h"
+#include "mpx_convw.h"
 #include "mpx_btail.h"
 #include "mpx_stemtab.h"
 #ifdef MPX_EXPERIMENTAL
@@ -592,6 +593,28 @@ int launch_convx(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     return 0;
 }
 
+// weights-in-registers expanding-1x1 kernel (mpx_convw.h, tile id 14): tile 10's layers with K = 256 exactly (a wave keeps the
+// 64 x 256 x (hi + lo) weights of its channels in 256 VGPRs); under one round of tiles the 128x128 kernel, as launch_convx
+bool convw_eligible(const ConvLayer& L) { return conv256_eligible(L) && L.cin_pad == ConvW::K; }
+
+int launch_convw(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
+    if (p.ktot != ConvW::K) return fail(h, MPX_E_INTERNAL, "convw: K = %d (the kernel holds K = %d in registers)", p.ktot, ConvW::K);
+    p.n_tiles_c = p.cout / ConvW::TC;
+    if (p.n_tiles_c * ConvW::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
+    const long long n_tiles_p = ((long long)p.M + ConvW::TP - 1) / ConvW::TP;
+    const long long total = n_tiles_p * p.n_tiles_c;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(h, MPX_E_ARG, "conv grid out of range");
+    long long grid = h->num_cus;
+    if (total < grid) grid = total;
+    const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
+    grid = grid / unit * unit;
+    if (grid <= 0 || total < 2LL * h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
+    hipLaunchKernelGGL(convw_f16x3_kernel, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
+    MPX_HIP(h, hipGetLastError());
+    h->last_kernels |= 1u << 14;
+    return 0;
+}
+
 #ifdef MPX_EXPERIMENTAL
 // X-stationary expanding-1x1 kernel (mpx_convs.h, tile id 11): 1x1 stride-1 layers with cout % 256 == 0 and K = 128 or 256
 bool convs_eligible(const ConvLayer& L) { return conv256_eligible(L) && (L.cin_pad == 128 || L.cin_pad == 256); }
@@ -761,6 +784,7 @@ int dispatch_conv(mpx_engine* h, const ConvLayer& L, ConvParams& p, int tile, hi
     }
     switch (tile) {
         case 10: return launch_convx(h, p, L.d.cout_pad, st);
+        case 14: return launch_convw(h, p, L.d.cout_pad, st);
         case 9: return launch_conv256(h, p, L.d.cout_pad, st);
         case 13: return launch_conv256p(h, p, L.d.cout_pad, st);
         case 0: return launch_conv_tile<ConvTile0>(h, p, L.d.cout_pad, st);
@@ -870,7 +894,7 @@ int launch_conv_fused(mpx_engine* h, int i, const half_t* in_hi, const half_t* i
 #ifdef MPX_EXPERIMENTAL
     if (L.tile == 8) return launch_convp_tile<ConvTile2, true>(h, p, L.d.cout_pad, st);
 #endif
-    return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);       // (tiles 7 and 10: the persistent kernel has no dual-operand form)
+    return launch_conv_tile<ConvTile7, true>(h, p, L.d.cout_pad, st);       // (tiles 7, 10 and 14: the persistent kernels have no dual-operand form)
 }
 
 // The ImageNet stem (7x7 stride-2 conv + BN + ReLU) with its 3x3 stride-2 pad-1 max pool in ONE launch (mpx_conv.h, POOL): writes the
@@ -1232,6 +1256,8 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convw_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv256p_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256P::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
@@ -1360,7 +1386,7 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
     // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13
-    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12 || tile == 13;
+    bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12 || tile == 13 || tile == 14;
 #ifdef MPX_EXPERIMENTAL
     known = known || tile == 3 || tile == 5 || tile == 8 || tile == 11;
     if (tile == 11 && !convs_eligible(L))
@@ -1368,11 +1394,13 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (tile == 8 && (L.is_fc || L.is_stem || L.d.cout < 128))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent kernel (8) runs conv layers with cout >= 128 (%s is not one)", L.d.name);
 #endif
-    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13)", tile);
+    if (!known) return fail(h, MPX_E_ARG, "set_conv_tile: unknown tile %d (product ids: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13, 14)", tile);
     if (tile == 13 && !conv256p_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent 256x256 kernel (13) runs 1x1 stride-1 layers with cout %% 256 == 0, cin %% 64 == 0 and no residual operand (%s is not one)", L.d.name);
     if (tile == 12 && !patchp_eligible(L.d))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent patch kernel (12) needs a 3x3 stride-1 layer with cout >= 128 and no residual operand whose input patch fits the LDS (%s is not one)", L.d.name);
+    if (tile == 14 && !convw_eligible(L))
+        return fail(h, MPX_E_ARG, "set_conv_tile: the weights-in-registers expanding-1x1 kernel (14) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin = 256 (%s is not one)", L.d.name);
     if (tile == 10 && !convx_eligible(L))
         return fail(h, MPX_E_ARG, "set_conv_tile: the persistent expanding-1x1 kernel (10) runs 1x1 stride-1 layers with cout %% 256 == 0 and cin %% 64 == 0, cin >= 128 (%s is not one)", L.d.name);
     if (tile == 9 && !conv256_eligible(L))
@@ -1665,7 +1693,7 @@ int mpx_forward(mpx_engine* h, const int32_t* label, float* score, int32_t* pred
                 if (h->fuse_ds && h->convs[o.conv].fuse_partner >= 0) {
                     const ConvLayer& CL = h->convs[o.conv];
                     const ConvLayer& MAIN = CL.fuse_main ? CL : h->convs[CL.fuse_partner];
-                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10 || MAIN.tile == 11)) {      // (8, 11: experimental builds)
+                    if (MAIN.fused_loaded && (MAIN.tile == 2 || MAIN.tile == 7 || MAIN.tile == 8 || MAIN.tile == 10 || MAIN.tile == 11 || MAIN.tile == 14)) {      // (8, 11: experimental builds)
                         if (!CL.fuse_main) break;       // the downsample conv runs inside its main conv's launch
                         rc = launch_conv_fused(h, o.conv, hi(o.in), lo(o.in), hi(o.in2), lo(o.in2), hi(o.out), lo(o.out), B, as_stream(stream));
                         break;

@@ -209,10 +209,10 @@ def test_conv_tile_ids_are_the_default_kernels(eng101):
     """The documented tile ids are exactly what default_tile hands out; the ids of kernels that never became a default (3, 5, 8, 11:
     probe builds only) and anything else are refused."""
     i = _layer_index(eng101, "layer3.5.conv3")
-    for tile in (3, 5, 8, 11, 14):
+    for tile in (3, 5, 8, 11, 15):
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, tile) == -1
     assert b"product ids" in eng101._lib.mpx_last_error(eng101._h)
-    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12, 13}
+    assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12, 13, 14}
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
@@ -249,6 +249,36 @@ def test_convx_persistent_expanding_kernel(eng101, name, batch):
     mask = eng101._lib.mpx_last_conv_kernels(eng101._h)
     tiles = -(-batch * d.hout * d.hout // 128) * (d.cout // 256)
     assert mask == (1 << 10 if tiles >= eng101.num_cus else 1 << 7), (mask, tiles)       # under one round of tiles: the 128x128 8-wave kernel
+
+
+@pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 47), ("layer3.5.conv3", 161), ("layer3.5.conv3", 5), ("layer3.22.conv3", 84),
+                                        ("layer2.1.conv3", 25), ("layer3.5.conv1", 9)])
+def test_convw_weights_in_registers_kernel(eng101, name, batch):
+    """Tile id 14 = the persistent expanding-1x1 kernel whose weights live in registers (csrc/mpx_convw.h): K = 256 only (128 -> 512 and
+    1024 -> 256 are refused), 64-pixel tiles, one barrier per tile.  Batches give a ragged last tile (47 images = 143.9 pixel tiles,
+    161 = 493.06) and from 2 to 8 tiles per workgroup; 84 images are 257.25 pixel tiles: workgroups with 4 and with 5; under two rounds
+    of tiles (5 images) the launch runs on the 128x128 8-wave kernel.  Against the fp64 conv + BN + residual + ReLU, and bit-equal to
+    tile 10 (the same order of summation and the same epilogue arithmetic) -- the test asserts which kernel ran."""
+    i = _layer_index(eng101, name)
+    d = eng101.layers[i]
+    if not (d.cin == 256 and d.cout % 256 == 0 and d.ksize == 1):
+        assert eng101._lib.mpx_set_conv_tile(eng101._h, i, 14) == -1
+        return
+    _check_layer(eng101, synth.make_state_dict("resnet101"), name, batch=batch, tile=14)
+    mask = eng101._lib.mpx_last_conv_kernels(eng101._h)
+    tiles = -(-batch * d.hout * d.hout // 64) * (d.cout // 256)
+    assert mask == (1 << 14 if tiles >= 2 * eng101.num_cus else 1 << 7), (mask, tiles)
+    g = torch.Generator().manual_seed(100 + batch)
+    x = torch.randn(batch, d.hin, d.hin, d.cin, generator=g).clamp_min(-0.5) * 1.5
+    res = torch.randn(batch, d.hout, d.hout, d.cout, generator=g)
+    outs = []
+    for tile in (14, 10):
+        eng101.set_conv_tile(i, tile)
+        try:
+            outs.append(_run_conv(eng101, i, x, res, batch, on_device=True)[0])
+        finally:
+            eng101.set_conv_tile(i, -1)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_stress_sweep_distinct_shapes(eng101):

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-TILE_IDS = (0, 1, 2, 4, 6, 7, 9, 10, 12, 13)          # what mpx_set_conv_tile accepts in the product build
+TILE_IDS = (0, 1, 2, 4, 6, 7, 9, 10, 12, 13, 14)          # what mpx_set_conv_tile accepts in the product build
 
 
 def distinct_shape_layers(eng):
