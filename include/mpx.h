@@ -105,6 +105,10 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
  *   9 = 256x256 tile, two 64-KB stages (reducing 1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0);
  *  10 = persistent pipelined 256x128 kernel, three stages running on across tiles (expanding 1x1 stride-1 layers with
  *       cout % 256 == 0, cin >= 128, on 28x28 / 14x14 maps);
+ *  14 = the expanding 1x1 kernel whose weights live in registers (csrc/mpx_convw.h): one persistent 4-wave workgroup per CU on
+ *       256 x 64 tiles, every wave keeps the 64 x 256 x (hi + lo) weights of its channels in 256 AGPRs, the LDS holds only two
+ *       whole pixel tiles (1x1 stride-1 layers with cout % 256 == 0 and cin = 256: the default of 256 -> 1024 on 14x14 maps;
+ *       bit-identical to 7 and 10);
  *  13 = the 256x256 kernel (9) as ONE persistent workgroup per CU: the two-stage ring runs on across tiles, register epilogue (layers
  *       eligible for 9 without a residual operand: their default; bit-identical to 9);
  *  12 = the patch kernel (6) as ONE persistent workgroup per CU: weight ring and patch buffers run on across tiles, register
@@ -116,8 +120,8 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
 int mpx_set_conv_tile(mpx_engine* h, int i, int tile);
 int mpx_get_conv_tile(const mpx_engine* h, int i);
 /* Test hook: which kernels the LAST mpx_conv_bn_act call launched, as a bit mask over the tile ids above (bit t = the kernel of tile
- * t ran).  A layer's tile is a request: a launch under one round of tiles of a persistent kernel (10, 12, 13) runs on the small-tile
- * kernel that sums in the same order (7, 6, 2), a residual operand sends 13 to 9, and the 256x256 kernels hand the images behind the
+ * t ran).  A layer's tile is a request: a launch under one round of tiles of a persistent kernel (10, 12, 13; 14: under two rounds) runs on the small-tile
+ * kernel that sums in the same order (7, 6, 2; 14: 7), a residual operand sends 13 to 9, and the 256x256 kernels hand the images behind the
  * last whole round to tile 2 -- so a test that means to cover a persistent walk asserts that it ran. */
 int mpx_last_conv_kernels(const mpx_engine* h);
 

@@ -758,6 +758,11 @@ int default_tile(const mpx_conv_desc& d) {
     // network; the reducing ones (long K) gain nothing from it
     // ... and on 28x28 / 14x14 maps with K >= 128 the persistent pipelined kernel (mpx_convx.h) is 2-4 % faster still in the
     // network (256->1024: 21.5 -> 21.0 ms, 128->512: 6.5 -> 6.2); on 7x7 maps and K = 64 it ties tile 7
+    // ... and with K = 256 exactly (256 -> 1024, a fifth of ResNet-101's conv time) the kernel that keeps the weights of a wave in its
+    // 256 AGPRs and only pixels in the LDS (mpx_convw.h): in the network at batch 2340, A/B in one call, 24.3 -> 21.3 ms for the 23 layers
+#ifndef MPX_PROBE_NO_CONVW               // A/B builds only (tools/ab_lib.sh)
+    if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout > d.cin && d.cout % 256 == 0 && d.cin == ConvW::K && d.hout >= 14) return 14;
+#endif
     if (d.ksize == 1 && d.stride == 1 && d.pad == 0 && d.cout > d.cin && d.cout % 256 == 0 && d.cin % 64 == 0 && d.cin >= 128 && d.hout >= 14)
         return 10;
     if (d.stride == 1 && d.cout > d.cin) return 7;
@@ -1385,7 +1390,7 @@ int mpx_set_conv_tile(mpx_engine* h, int i, int tile) {
     if (i < 0 || i >= (int)h->convs.size()) return fail(h, MPX_E_ARG, "set_conv_tile: bad layer index");
     ConvLayer& L = h->convs[i];
     if (tile < 0) tile = default_tile(L.d);
-    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13
+    // product ids = what default_tile can return: 0, 1, 2, 4, 6, 7, 9, 10, 12, 13, 14
     bool known = tile == 0 || tile == 1 || tile == 2 || tile == 4 || tile == 6 || tile == 7 || tile == 9 || tile == 10 || tile == 12 || tile == 13 || tile == 14;
 #ifdef MPX_EXPERIMENTAL
     known = known || tile == 3 || tile == 5 || tile == 8 || tile == 11;

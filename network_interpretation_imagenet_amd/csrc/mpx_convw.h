@@ -11,13 +11,14 @@
 //   * tile 256 (cout) x 64 (pixels), 4 waves (one per SIMD, 512 registers each), wave w owns channels [64 w, 64 w + 64) of the cout
 //     tile for ALL pixels: its 8 x 4 x (hi, lo) weight fragments are loaded ONCE per launch, straight from the piece-major planes in
 //     MFMA operand layout, and never touch the LDS;
-//   * the LDS holds only pixels: two buffers of a whole 64-pixel x 256-channel tile (8 K steps x [X_hi 4 KB | X_lo 4 KB] = 64 KB),
-//     the next tile lands while the current one is multiplied -- 16 DMA pieces per wave and tile instead of 48 per half-tile, a third
-//     of the L2 -> LDS bytes per MAC, and the K loop has no barrier and no counted wait (one barrier per TILE);
+//   * the LDS holds only pixels: two buffers of a whole 64-pixel x 256-channel tile (8 K steps x [X_hi 4 KB | X_lo 4 KB] = 64 KB);
+//     a tile is requested a whole tile ahead, between the slices of the epilogue that releases its buffer -- 16 DMA pieces per wave
+//     and tile instead of 48 per half-tile, a third of the L2 -> LDS bytes per MAC; the K loop has no barrier, no DMA and no counted
+//     wait (one vmcnt(0) and one barrier per TILE);
 //   * pixel fragments are single-buffered and re-read column by column: when the 12 MFMAs of a pixel column are issued its two
 //     registers quads take the next K step's fragments (36 MFMAs of slack);
 //   * epilogue from the accumulator registers as mpx_convx.h (v_permlane16_swap + DPP row_ror:8 regrouping into whole 128-B lines),
-//     residual lines requested four K steps before the tile ends.
+//     residual lines requested four K steps before the tile ends (ConvW::RES_STEP: earlier is slower).
 // Per accumulator the products are summed in tile 10's order (K steps ascending; hi*lo, lo*hi, hi*hi), and the epilogue arithmetic is
 // the same: results are bit-identical to tiles 7 and 10.
 #pragma once
@@ -49,6 +50,11 @@ struct ConvW {
     static constexpr int TILE = NK * STAGE;             // 64 KB
     static constexpr int OFF_SCALE = 2 * TILE;          // f32[256] scale, f32[256] shift of the workgroup's cout tile
     static constexpr int LDS = 2 * TILE + 2048;
+    // K step behind whose first pixel column a tile's residual lines are requested.  Measured in the network at batch 2340 (two passes
+    // of tools/ab_variants.sh in one call, the 23 layers 256 -> 1024): step 0: 23.9 ms, 2: 21.7, 3: 21.3, 4: 21.25, 5: 21.9, 6: 22.7 --
+    // EARLIER is slower although nothing waits for the lines before the epilogue: the chip's workgroups run in step, and residual reads
+    // that start while the previous tile's stores still drain mix reads and writes at the DRAM
+    static constexpr int RES_STEP = 4;
 };
 
 __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p) {
@@ -130,6 +136,8 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
     const int row8 = 8 * p.cout * 2;
     u4 rh[4][2], rl[4][2];
     f4 acc[4][4];
+    float one = 1.0f;                           // opaque to the optimiser (fma(x, one, y) must stay an fma for v_fma_mix_f32)
+    asm volatile("" : "+v"(one));
     auto ror8 = [](float old, float src, auto mask_tag) {
         constexpr int MASK = decltype(mask_tag)::value;
         return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(src), 0x128, 0xf, MASK, false));
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                 rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, offA[b] + k * row8, 0, 2);
             }
     };
-    auto epilogue = [&](int ti) {               // 16 stores
+    auto epilogue = [&](int ti, auto&& after_slice) {               // 16 stores
         const int m0 = (mt0 + ti * mt_step) * C::TP;
         const long long rem = ((long long)p.M - m0) * p.cout * 2;
         const int rec = rem > 0x7fffffffLL ? 0x7fffffff : (int)rem;
@@ -185,10 +193,13 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                 for (int j = 0; j < 8; ++j)
                     v[j] = k == 0 ? ror8(ve[j], vo[j], std::integral_constant<int, 0xC>{}) : ror8(vo[j], ve[j], std::integral_constant<int, 0x3>{});
                 {
-                    const h8 a = __builtin_bit_cast(h8, rh[b][k]);     // zeros when the layer has no residual
+                    // + (hi + lo) of the residual line (zeros when the layer has no residual).  hi + lo is exact in fp32, and with `one`
+                    // opaque it is ONE v_fma_mix_f32 (both fp16 -> fp32 conversions ride in the instruction) instead of two conversions
+                    // and an addition: the same value, so the same bits as mpx_convx.h's v + ((float)hi + (float)lo)
+                    const h8 a = __builtin_bit_cast(h8, rh[b][k]);
                     const h8 c = __builtin_bit_cast(h8, rl[b][k]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)a[j] + (float)c[j];
+                    for (int j = 0; j < 8; ++j) v[j] += __builtin_fmaf((float)a[j], one, (float)c[j]);
                 }
                 if (p.relu) {
 #pragma unroll
@@ -196,15 +207,15 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                 }
                 h8 oh, ol;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    half_t hi, lo;
-                    split_f32(v[j], hi, lo);
+                for (int j = 0; j < 8; ++j) {       // split_f32 with v - (float)hi as one v_fma_mix (exact either way: the same bits)
+                    const half_t hi = (half_t)v[j];
                     oh[j] = hi;
-                    ol[j] = lo;
+                    ol[j] = (half_t)__builtin_fmaf((float)hi, -one, v[j]);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[b] + k * row8, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[b] + k * row8, 0, 2);
             }
+            after_slice(b);
         }
     };
 
@@ -214,10 +225,16 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         *(f4*)(smem + C::OFF_SCALE + tid * 16) = *(const f4*)src;
     }
     // ---- prologue: the whole first pixel tile into buffer 0 (the weight loads above are in flight next to it) -----------------
+    // ---- prologue: the first TWO pixel tiles into the two buffers (the weight loads above are in flight next to them) -----------
     set_x_desc(0);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) dma_stage(0, ks);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    set_x_desc(1);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) dma_stage(1, ks);
+    // (the builtin, not an asm statement: hipcc's own wait insertion then knows that the weight loads have returned -- behind an asm
+    // wait it guards the first use of every weight register in the tile loop with a vmcnt(N) that the loop's own loads run into)
+    __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -225,8 +242,8 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
 
     int buf = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        set_x_desc(ti + 1);                     // the tile fetched during this K loop goes to the other buffer
         const int nbuf = buf ^ 1;
+        set_x_desc(ti + 2);                     // requested under this tile's epilogue, into this tile's buffer
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
@@ -248,30 +265,31 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                     read_b(buf, ks + 1, b);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // K steps 0..3: one stage of the next tile per column pair (4 pieces per step, 16 per tile)
-                if (ks < 4 && (b & 1) == 1) {
-                    dma_stage(nbuf, 2 * ks + (b >> 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // K step 4: this tile's residual lines, behind every piece of the next tile
-                if (ks == 4 && b == 0) {
+                if (ks == C::RES_STEP && b == 0) {
                     issue_epilogue_loads(ti);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        // every piece of the next tile and every residual line of this one has landed; behind the barrier all four waves' pieces have,
-        // and nobody reads this tile's buffer again (the tile after next is fetched into it from the next K loop on)
+        // Loads, LDS-DMAs and stores retire in issue order: behind vmcnt(0) this tile's residual lines are here and this wave's pieces
+        // of the next tile (requested a whole tile ago) have landed; behind the barrier all four waves' pieces have, and nobody reads
+        // this tile's buffer again.
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mfma_drain();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // the first fragments of the next tile travel under the epilogue (past the last tile: zeros of the dead pieces, unused)
+        // the first fragments of the next tile travel under the epilogue (past the last tile: stale bytes, unused) ...
 #pragma unroll
         for (int b = 0; b < 4; ++b) read_b(nbuf, 0, b);
         __builtin_amdgcn_sched_barrier(0);
-        epilogue(ti);
+        // ... and the tile after next is requested between its four slices, into the buffer that has just been released
+        epilogue(ti, [&](int b) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_stage(buf, 2 * b);
+            dma_stage(buf, 2 * b + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         buf = nbuf;
     }

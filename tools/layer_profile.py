@@ -32,7 +32,7 @@ if os.environ.get("MPX_TILE_PATCH"):      # tool-only override: patch kernel (ti
             eng.set_conv_tile(i, 6)
         except MpxError:
             pass
-if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with classes k1exp k1red k1s2 k3s1 k3s2 c64k1 c64k3 stem k1x (= default tile 10)
+if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with classes k1exp k1red k1s2 k3s1 k3s2 c64k1 c64k3 stem k1x (= default tile 10 or 14)
     rules = dict(r.split(":") for r in os.environ["MPX_TILE_RULES"].split(","))
     took, kept = {}, {}
     for i, d in enumerate(eng.layers):
@@ -46,7 +46,7 @@ if os.environ.get("MPX_TILE_RULES"):     # tool-only: "class:tile,..." with clas
             cls = "k1s2"
         else:
             cls = "k1exp" if d.cout > d.cin else "k1red"
-        if "k1x" in rules and eng.conv_tile(i) == 10:           # the layers whose default is the persistent expanding kernel (256->1024, 128->512)
+        if "k1x" in rules and eng.conv_tile(i) in (10, 14):         # the layers whose default is the persistent expanding kernel (256->1024, 128->512)
             cls = "k1x"
         if cls in rules and d.name != b"fc":
             try:
