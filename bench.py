@@ -376,7 +376,7 @@ def main(argv=None):
                         "traffic": (traffic_per_batch / (conv_n / forwards_profiled)) if traffic_per_batch else None,
                         # NOT measured in this run: PMC counters need rocprofv3; the file holds the per-batch bytes of the same forward
                         "traffic_source": traffic_source, "traffic_bytes_per_forward_batch": traffic_per_batch,
-                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv3x3pp_f16x3_kernel + conv256_f16x3_kernel + convx_f16x3_kernel + btail_f16x3_kernel"
+                        "kernel": "conv_f16x3_kernel + conv3x3p_f16x3_kernel + conv3x3pp_f16x3_kernel + conv256_f16x3_kernel + conv256p_f16x3_kernel + convx_f16x3_kernel + convw_f16x3_kernel + btail_f16x3_kernel"
                                   + (" + stem_apply_kernel (conv1 + bn1 + relu + maxpool of all masks of an image from its superposition table)" if eng.stem == "table" else "")
                                   + " (all conv launches)", "launches": conv_n,
                         "avg_launch_us": conv_ms * 1e3 / conv_n,

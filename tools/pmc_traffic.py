@@ -32,7 +32,7 @@ write = w * 1024 / nb
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) --kernel-trace -- python3 tools/layer_profile.py "
               "%s %d; every kernel whose name contains _f16x3_kernel = all conv launches (conv_f16x3_kernel, conv3x3p_f16x3_kernel, conv3x3pp_f16x3_kernel, "
-              "conv256_f16x3_kernel, convx_f16x3_kernel, btail_f16x3_kernel) + stem_apply_kernel (the stem by superposition, when the profile staged that way), per forward batch of %d masked images" % (arch, batch, batch),
+              "conv256_f16x3_kernel, conv256p_f16x3_kernel, convx_f16x3_kernel, convw_f16x3_kernel, btail_f16x3_kernel) + stem_apply_kernel (the stem by superposition, when the profile staged that way), per forward batch of %d masked images" % (arch, batch, batch),
     "arch": arch,
     "forward_batch": batch,
     # kernel dispatches the counters were summed over: a layer whose last round of tiles is split off runs as two dispatches, so this
