@@ -609,7 +609,8 @@ int launch_convw(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
     grid = grid / unit * unit;
     if (grid <= 0 || total < 2LL * h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
-    hipLaunchKernelGGL(convw_f16x3_kernel, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
+    if (p.relu) hipLaunchKernelGGL(convw_f16x3_kernel<true>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
+    else hipLaunchKernelGGL(convw_f16x3_kernel<false>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     h->last_kernels |= 1u << 14;
     return 0;
@@ -1261,7 +1262,9 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convx_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvX::LDS);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convw_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
+        e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv256p_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256P::LDS);
     if (e == hipSuccess)

@@ -43,6 +43,37 @@ __device__ __forceinline__ void mfma_drain() {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
+// Epilogue arithmetic of a 1-wave-per-SIMD kernel, where every VALU instruction is exposed: the forms hipcc does not pick by itself
+// (its SLP pass packs these chains into v_pk_fma_f32 / v_pk_add_f32 behind separate conversions).  Same values, same bits:
+//   hi + lo of a residual element is exact in fp32, so ONE v_fma_mix_f32 (both fp16 -> fp32 conversions ride in the instruction) gives
+//   what (float)hi + (float)lo gives; v - (float)fp16(v) is exact, so v_fma_mixlo/hi_f16 round the same number split_f32 rounds.
+__device__ __forceinline__ float cw_pair_lo(unsigned h, float one, unsigned l) {      // (float)lo16(h) + (float)lo16(l)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(one), "v"(l));
+    return d;
+}
+__device__ __forceinline__ float cw_pair_hi(unsigned h, float one, unsigned l) {      // (float)hi16(h) + (float)hi16(l)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(one), "v"(l));
+    return d;
+}
+__device__ __forceinline__ float cw_relu(float v) {
+    float d;
+    asm("v_max_f32 %0, 0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+__device__ __forceinline__ unsigned cw_pack_hi(float a, float b) {                    // {fp16(a), fp16(b)}
+    unsigned d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned cw_pack_lo(unsigned hi, float one, float a, float b) {   // {fp16(a - lo16(hi)), fp16(b - hi16(hi))}
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -%2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -%2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(hi), "v"(one), "v"(a), "v"(b));
+    return d;
+}
+
 struct ConvW {
     static constexpr int TC = 256, TP = 64, NW = 4, NT = 256;
     static constexpr int K = 256, NK = K / 32;
@@ -57,6 +88,7 @@ struct ConvW {
     static constexpr int RES_STEP = 4;
 };
 
+template <bool RELU>
 __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,28 +224,21 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     v[j] = k == 0 ? ror8(ve[j], vo[j], std::integral_constant<int, 0xC>{}) : ror8(vo[j], ve[j], std::integral_constant<int, 0x3>{});
-                {
-                    // + (hi + lo) of the residual line (zeros when the layer has no residual).  hi + lo is exact in fp32, and with `one`
-                    // opaque it is ONE v_fma_mix_f32 (both fp16 -> fp32 conversions ride in the instruction) instead of two conversions
-                    // and an addition: the same value, so the same bits as mpx_convx.h's v + ((float)hi + (float)lo)
-                    const h8 a = __builtin_bit_cast(h8, rh[b][k]);
-                    const h8 c = __builtin_bit_cast(h8, rl[b][k]);
+                // + (hi + lo) of the residual line (zeros when the layer has no residual), ReLU, split into hi + lo (cw_* above)
+                u4 oh, ol;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += __builtin_fmaf((float)a[j], one, (float)c[j]);
+                for (int q = 0; q < 4; ++q) {
+                    float r0 = v[2 * q] + cw_pair_lo(rh[b][k][q], one, rl[b][k][q]);
+                    float r1 = v[2 * q + 1] + cw_pair_hi(rh[b][k][q], one, rl[b][k][q]);
+                    if (RELU) {
+                        r0 = cw_relu(r0);
+                        r1 = cw_relu(r1);
+                    }
+                    oh[q] = cw_pack_hi(r0, r1);
+                    ol[q] = cw_pack_lo(oh[q], one, r0, r1);
                 }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                h8 oh, ol;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {       // split_f32 with v - (float)hi as one v_fma_mix (exact either way: the same bits)
-                    const half_t hi = (half_t)v[j];
-                    oh[j] = hi;
-                    ol[j] = (half_t)__builtin_fmaf((float)hi, -one, v[j]);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, offA[b] + k * row8, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, offA[b] + k * row8, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(oh, y_hi_rs, offA[b] + k * row8, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, y_lo_rs, offA[b] + k * row8, 0, 2);
             }
             after_slice(b);
         }
