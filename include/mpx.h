@@ -104,7 +104,7 @@ int mpx_weights_complete(const mpx_engine* h);     /* 1 when every layer has wei
  *       K = 64 or on 7x7 maps, and the K-concatenated conv3 + downsample launches);
  *   9 = 256x256 tile, two 64-KB stages (reducing 1x1 stride-1 layers with cout % 256 == 0, cin % 64 == 0);
  *  10 = persistent pipelined 256x128 kernel, three stages running on across tiles (expanding 1x1 stride-1 layers with
- *       cout % 256 == 0, cin >= 128, on 28x28 / 14x14 maps);
+ *       cout % 256 == 0, cin >= 128 that tile 14 does not take: 128 -> 512, 512 -> 2048);
  *  14 = the expanding 1x1 kernel whose weights live in registers (csrc/mpx_convw.h): one persistent 4-wave workgroup per CU on
  *       256 x 64 tiles, every wave keeps the 64 x 256 x (hi + lo) weights of its channels in 256 AGPRs, the LDS holds only two
  *       whole pixel tiles (1x1 stride-1 layers with cout % 256 == 0 and cin = 256: the default of 256 -> 1024 on 14x14 maps;
