@@ -91,7 +91,7 @@ prof = eng.collect_profile()
 tot = 0.0
 groups = {}
 print("%-26s %5s %5s %2s %2s %4s %9s %9s %8s" % ("layer", "cin", "cout", "k", "s", "hout", "ms", "GFLOP", "TFLOP/s"))
-for d, ms in zip(eng.layers, prof["per_conv_ms"]):
+for li, (d, ms) in enumerate(zip(eng.layers, prof["per_conv_ms"])):
     ms /= reps
     fl = 2.0 * batch * d.hout * d.hout * d.cout * d.cin * d.ksize * d.ksize
     key = (d.cin, d.cout, d.ksize, d.stride, d.hout)
@@ -100,6 +100,8 @@ for d, ms in zip(eng.layers, prof["per_conv_ms"]):
     a[1] += ms
     a[2] += fl
     tot += ms
+    if os.environ.get("MPX_PER_LAYER"):     # tool-only: one row per conv (a fused launch is booked on its main conv)
+        print("%-26s %5d %5d %2d %2d %4d %9.3f %9.1f %8.1f   tile %d" % (d.name.decode(), d.cin, d.cout, d.ksize, d.stride, d.hout, ms, fl / 1e9, fl / max(ms, 1e-9) / 1e9, eng.conv_tile(li)))
 print("-- grouped by shape --")
 for key, (n, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     print("%5d->%-5d k%d s%d out%-4d x%-3d %8.3f ms %5.1f%% %8.1f TFLOP/s%s" % (key[0], key[1], key[2], key[3], key[4], n, ms, 100 * ms / tot, fl / max(ms, 1e-9) / 1e9,
