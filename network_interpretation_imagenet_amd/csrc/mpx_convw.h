@@ -7,7 +7,7 @@
 // LDS-DMA pieces re-stream the SAME 256 KB of weights through L2 -> LDS for every pixel tile a workgroup walks -- 47 B of operand
 // traffic per 1000 MACs against 16 for the 3x3 patch kernel, at the package power limit with the MFMA pipe a third busy.  A
 // persistent workgroup keeps its cout tile for the whole launch, and with K = 256 the weights of 64 output channels are
-// 64 x 256 x (hi + lo) = 64 KB = 256 VGPRs of one wave.  Here:
+// 64 x 256 x (hi + lo) = 64 KB = the 256 AGPRs of one wave.  Here:
 //   * tile 256 (cout) x 64 (pixels), 4 waves (one per SIMD, 512 registers each), wave w owns channels [64 w, 64 w + 64) of the cout
 //     tile for ALL pixels: its 8 x 4 x (hi, lo) weight fragments are loaded ONCE per launch, straight from the piece-major planes in
 //     MFMA operand layout, and never touch the LDS;
@@ -18,7 +18,8 @@
 //   * pixel fragments are single-buffered and re-read column by column: when the 12 MFMAs of a pixel column are issued its two
 //     registers quads take the next K step's fragments (36 MFMAs of slack);
 //   * epilogue from the accumulator registers as mpx_convx.h (v_permlane16_swap + DPP row_ror:8 regrouping into whole 128-B lines),
-//     residual lines requested four K steps before the tile ends (ConvW::RES_STEP: earlier is slower).
+//     residual lines requested four K steps before the tile ends (ConvW::RES_STEP: earlier is slower), the 16 stores of a tile in
+//     one burst behind the arithmetic.
 // Per accumulator the products are summed in tile 10's order (K steps ascending; hi*lo, lo*hi, hi*hi), and the epilogue arithmetic is
 // the same: results are bit-identical to tiles 7 and 10.
 #pragma once
