@@ -61,6 +61,69 @@ def test_build_stamp_covers_every_source(tmp_path):
     assert g._stale(lib, g.lib_sources(str(root)), g.HIPCC_FLAGS)      # a new header is picked up by the glob
 
 
+def _device_kernels(lib_path):
+    """(name -> metadata dict) of the gfx950 code object inside a HIP fat binary: the clang offload bundle is located by its magic,
+    the AMDGPU metadata note is printed by llvm-readelf (no GPU needed)."""
+    import struct
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not installed")
+    blob = open(lib_path, "rb").read()
+    i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0, "no offload bundle in %s" % lib_path
+    n = struct.unpack_from("<Q", blob, i + 24)[0]
+    off, elf = i + 32, None
+    for _ in range(n):
+        o, size, tl = struct.unpack_from("<QQQ", blob, off)
+        off += 24
+        triple = blob[off:off + tl].decode()
+        off += tl
+        if "gfx950" in triple:
+            elf = blob[i + o:i + o + size]
+    assert elf, "no gfx950 code object in the bundle"
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".elf") as fh:
+        fh.write(elf)
+        fh.flush()
+        notes = subprocess.run([readelf, "--notes", fh.name], capture_output=True, text=True, check=True).stdout
+    kernels, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*(?:- )?\.(\w+):\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "agpr_count" and line.lstrip().startswith("-"):
+            cur = {}
+        if cur is not None:
+            cur[key] = val
+            if key == "name":
+                kernels[val] = cur
+    return kernels
+
+
+def test_conv_kernels_have_no_scratch_and_convw_keeps_its_weights_in_agprs(mpx_lib):
+    """Static guard on what hipcc made of the hand-scheduled kernels (read from the built library, no GPU): a scratch reload inside a K loop
+    drains vmcnt and breaks the counted waits, and the weights-in-registers kernel (csrc/mpx_convw.h) is only what its name says while the
+    256 weight registers of a wave are the whole AGPR half of its file and nothing spills."""
+    ks = _device_kernels(_lib.LIB_PATH)
+    conv = {n: k for n, k in ks.items() if "_f16x3_kernel" in n}
+    assert len(conv) >= 15, sorted(ks)
+    for n, k in conv.items():
+        scratch = int(k["private_segment_fixed_size"])
+        if any(t in n for t in ("convw_", "convx_", "conv256p_", "conv3x3pp_", "btail_")):
+            # the persistent kernels: their tile loop IS the K loop, a spill anywhere in it is a reload between MFMAs
+            assert scratch == 0 and int(k.get("vgpr_spill_count", 0)) == 0, "%s: %d bytes of scratch per lane" % (n, scratch)
+        else:
+            # one workgroup per tile: hipcc parks a few prologue values across the K loop (stored before the first MFMA, reloaded behind
+            # the last one -- checked in the ISA); more than that would mean spills inside the loop
+            assert scratch <= 72, "%s: %d bytes of scratch per lane" % (n, scratch)
+    convw = {n: k for n, k in conv.items() if "convw_f16x3_kernel" in n}
+    assert len(convw) == 2, sorted(conv)                  # RELU = true / false
+    for n, k in convw.items():
+        assert int(k["agpr_count"]) == 256 and int(k["vgpr_count"]) <= 512, (n, k)
+
+
 def test_null_engine_calls_fail_cleanly(mpx_lib):
     assert mpx_lib.mpx_num_convs(None) == -1
     assert mpx_lib.mpx_forward(None, None, None, None, None, 1, None) == -1
