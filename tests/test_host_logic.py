@@ -61,14 +61,12 @@ def test_build_stamp_covers_every_source(tmp_path):
     assert g._stale(lib, g.lib_sources(str(root)), g.HIPCC_FLAGS)      # a new header is picked up by the glob
 
 
-def _device_kernels(lib_path):
-    """(name -> metadata dict) of the gfx950 code object inside a HIP fat binary: the clang offload bundle is located by its magic,
-    the AMDGPU metadata note is printed by llvm-readelf (no GPU needed)."""
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _device_elf(lib_path):
+    """the gfx950 code object inside a HIP fat binary (the clang offload bundle is located by its magic)"""
     import struct
-    import subprocess
-    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
-    if not os.path.exists(readelf):
-        pytest.skip("llvm-readelf not installed")
     blob = open(lib_path, "rb").read()
     i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
     assert i >= 0, "no offload bundle in %s" % lib_path
@@ -82,7 +80,17 @@ def _device_kernels(lib_path):
         if "gfx950" in triple:
             elf = blob[i + o:i + o + size]
     assert elf, "no gfx950 code object in the bundle"
+    return elf
+
+
+def _device_kernels(lib_path):
+    """(name -> metadata dict) of that code object: the AMDGPU metadata note as llvm-readelf prints it (no GPU needed)"""
+    import subprocess
     import tempfile
+    readelf = os.path.join(LLVM_BIN, "llvm-readelf")
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not installed")
+    elf = _device_elf(lib_path)
     with tempfile.NamedTemporaryFile(suffix=".elf") as fh:
         fh.write(elf)
         fh.flush()
@@ -122,6 +130,35 @@ def test_conv_kernels_have_no_scratch_and_convw_keeps_its_weights_in_agprs(mpx_l
     assert len(convw) == 2, sorted(conv)                  # RELU = true / false
     for n, k in convw.items():
         assert int(k["agpr_count"]) == 256 and int(k["vgpr_count"]) <= 512, (n, k)
+
+
+def test_convw_k_loop_is_what_the_source_says():
+    """The three things hipcc did to the first builds of csrc/mpx_convw.h and the source now prevents, checked in the disassembly of the
+    built library: between the first and the last MFMA of the tile loop there is no v_accvgpr copy (the weights are MFMA operands IN the
+    AGPRs: inline asm with an "a" constraint), no s_waitcnt vmcnt (the weight loads are known to have returned: waitcnt builtin in the
+    prologue) and no scratch access; a tile is 8 K steps x 48 MFMAs, every one with an AGPR A operand."""
+    import subprocess
+    import tempfile
+    objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not installed")
+    import __graft_entry__ as g
+    g.build()
+    with tempfile.NamedTemporaryFile(suffix=".elf") as fh:
+        fh.write(_device_elf(_lib.LIB_PATH))
+        fh.flush()
+        asm = subprocess.run([objdump, "-d", fh.name], capture_output=True, text=True, check=True).stdout
+    for relu in ("ILb1E", "ILb0E"):
+        m = re.search(r"<_ZN3mpx18convw_f16x3_kernel%sEEvNS_10ConvParamsE>:\n(.*?)\n\n" % relu, asm, re.S)
+        assert m, "kernel not found in the disassembly"
+        ins = [l.split("//")[0].strip() for l in m.group(1).splitlines()]
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f32_16x16x32_f16")]
+        assert len(mf) == 384, len(mf)
+        assert all(re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\]", ins[i]) for i in mf), "an MFMA without an AGPR A operand"
+        loop = ins[mf[0]:mf[-1] + 1]
+        assert not [l for l in loop if "v_accvgpr" in l], "AGPR copies in the K loop"
+        assert not [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l], "a vmcnt wait in the K loop"
+        assert not [l for l in loop if l.startswith("scratch_")], "scratch access in the K loop"
 
 
 def test_null_engine_calls_fail_cleanly(mpx_lib):
