@@ -84,8 +84,8 @@ struct ConvW {
     static constexpr int LDS = 2 * TILE + 2048;
     // K step behind whose first pixel column a tile's residual lines are requested.  Measured in the network at batch 2340 (two passes
     // of tools/ab_variants.sh in one call, the 23 layers 256 -> 1024): step 0: 23.9 ms, 2: 21.7, 3: 21.3, 4: 21.25, 5: 21.9, 6: 22.7 --
-    // EARLIER is slower although nothing waits for the lines before the epilogue: the chip's workgroups run in step, and residual reads
-    // that start while the previous tile's stores still drain mix reads and writes at the DRAM
+    // EARLIER is slower although nothing waits for the lines before the epilogue (measured, not explained by a bare copy
+    // kernel's behaviour; the order and timing of a wave's memory instructions decide this layer, not their number)
     static constexpr int RES_STEP = 4;
 };
 
