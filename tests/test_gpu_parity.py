@@ -213,6 +213,9 @@ def test_conv_tile_ids_are_the_default_kernels(eng101):
         assert eng101._lib.mpx_set_conv_tile(eng101._h, i, tile) == -1
     assert b"product ids" in eng101._lib.mpx_last_error(eng101._h)
     assert {eng101.conv_tile(j) for j in range(len(eng101.layers))} <= {0, 1, 2, 4, 6, 7, 9, 10, 12, 13, 14}
+    # the defaults of the expanding 1x1 layers: K = 256 on the weights-in-registers kernel, the other K >= 128 ones (7x7 maps included) on tile 10
+    for name, tile in (("layer3.5.conv3", 14), ("layer3.22.conv3", 14), ("layer2.1.conv3", 10), ("layer4.1.conv3", 10), ("layer1.1.conv3", 7)):
+        assert eng101.conv_tile(_layer_index(eng101, name)) == tile, name
 
 
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 5), ("layer3.5.conv3", 47), ("layer3.5.conv1", 13), ("layer2.1.conv3", 3),
