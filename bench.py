@@ -130,14 +130,26 @@ def cpu_baseline(arch, n_masks, eng=None):
     if eng is not None:
         img, seg, onoff = _cpu_inputs(n_masks)
         label, _p = eng.predict(img)                    # the reference scores the class the unmasked image is predicted as
-        _o, g_score, g_pred = eng.score_masks(img, seg, onoff, label)
+        # the sample goes through the staging the TIMED step used (eng.stem: the stem table by default -- 16 rows alone would fall under
+        # the engine's 256-row threshold and take K0 + the MFMA stem), and through the other staging as a second field
+        _o, g_score, g_pred = eng.score_masks(img, seg, onoff, label, stem=eng.stem)
+        other = "conv" if eng.stem == "table" else None
+        if other:
+            _o, o_score, o_pred = eng.score_masks(img, seg, onoff, label, stem=other)
     v, dt, c_score, c_pred = _cpu_loop(arch, n_masks, all_threads, label)
     if eng is not None:
-        parity = {"score_max_abs_delta": float(np.abs(g_score.astype(np.float64) - c_score.astype(np.float64)).max()),
+        delta = lambda s: float(np.abs(s.astype(np.float64) - c_score.astype(np.float64)).max())
+        parity = {"score_max_abs_delta": delta(g_score),
                   "argmax_agree": bool((g_pred == c_pred).all()), "tolerance": 1e-4,
-                  "sample": "%s, 1 noise image x %d masks (the cpu_baseline sample), label = unmasked argmax %d: engine.score_masks "
-                            "against the batch-1 fp32 torch-CPU loop (oracle/scorer.py)" % (arch, n_masks, label),
+                  "staging": "%s (the staging of the timed step: %s)" % (eng.stem, "mpx_stem_table_build + mpx_stem_table_apply" if eng.stem == "table"
+                                                                          else "mpx_mask_apply_normalize + the MFMA stem"),
+                  "sample": "%s, 1 noise image x %d masks (the cpu_baseline sample), label = unmasked argmax %d: engine.score_masks(stem=%r) "
+                            "against the batch-1 fp32 torch-CPU loop (oracle/scorer.py)" % (arch, n_masks, label, eng.stem),
                   "score_range": [float(c_score.min()), float(c_score.max())]}
+        if other:
+            parity["other_staging"] = {"staging": "conv (mpx_mask_apply_normalize + the MFMA stem: what a call under %d rows per image takes)" % eng.stem_table_min_rows,
+                                       "score_max_abs_delta": delta(o_score), "argmax_agree": bool((o_pred == c_pred).all()),
+                                       "max_abs_delta_between_stagings": float(np.abs(o_score.astype(np.float64) - g_score.astype(np.float64)).max())}
     c1_all, dt_all, _s, _p = _cpu_loop("resnet18", 64, all_threads)
     c1_one, dt_one, _s, _p = _cpu_loop("resnet18", 16, 1)
     torch.set_num_threads(all_threads)
@@ -160,14 +172,18 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, stub=False, grace_s=10.0):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), wait for them, and
-    return a non-zero code if any failed (the others are then terminated).  Rank 0's JSON line reaches stdout because the
-    children inherit it.  This parent never touches a GPU -- it builds the library (hipcc only), spawns and waits -- and
-    nothing is exec'ed from a process that has initialised one."""
-    import __graft_entry__ as g
-    g.build()                   # once, before the ranks start (they find a fresh stamp and only load it)
+    return a non-zero code if any failed.  The others are then sent SIGTERM and, if they have not exited `grace_s` seconds later (a rank
+    blocked in a collective or a kernel does not see the signal), SIGKILL; whatever ends this function -- an exception, Ctrl-C -- every
+    child is reaped on the way out.  Rank 0's JSON line reaches stdout because the children inherit it.  This parent never touches
+    a GPU: it only COMPILES the library when its stamp is stale (hipcc; the ranks then find a fresh stamp and load it themselves) --
+    it does not dlopen it, so no HIP runtime is initialised here and nothing is exec'ed from a process that has one.  With the stub step
+    (`--stub-step`, the CPU test hook) nothing is compiled at all."""
+    if not stub:
+        import __graft_entry__ as g
+        g.compile_only()
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("MASTER_PORT", str(_free_port()))
@@ -175,25 +191,41 @@ def launch_ranks(n, argv):
     env["WORLD_SIZE"] = str(n)
     env["LOCAL_WORLD_SIZE"] = str(n)
     procs = []
-    for r in range(n):
-        e = dict(env)
-        e["RANK"] = e["LOCAL_RANK"] = str(r)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
     rc = 0
-    pending = set(range(n))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+    try:
+        for r in range(n):
+            e = dict(env)
+            e["RANK"] = e["LOCAL_RANK"] = str(r)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+        pending = set(range(n))
+        kill_at = None
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()
+                    kill_at = time.monotonic() + grace_s
+            if pending and kill_at is not None and time.monotonic() >= kill_at:
                 for q in pending:
-                    procs[q].terminate()
-        if pending:
-            time.sleep(0.05)
+                    sys.stderr.write("bench.py: rank %d ignored SIGTERM for %.0f s; killing it\n" % (q, grace_s))
+                    procs[q].kill()
+                kill_at = float("inf")
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for p in procs:                     # an exception or Ctrl-C in the loop above must not leave ranks behind
+            if p.poll() is None:
+                p.kill()
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
     return rc
 
 
@@ -264,7 +296,7 @@ def main(argv=None):
     args = parse(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started without a launcher: this process becomes one (it never initialises a GPU)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv, stub=args.stub_step))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -285,8 +285,10 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
                            const int32_t* label, int M, int S, float* heat, void* stream);
 
 /* ---- introspection for tests / benchmarks --------------------------------------------------- */
-/* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4]. */
-int mpx_input_planes(const mpx_engine* h, void** hi, void** lo);
+/* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4].  A caller may write them (tests do): the call marks
+ * every slot as staged through these planes, so the next mpx_forward runs the stem conv + max pool on them even if an earlier batch of the
+ * same slots came from mpx_stem_table_apply (which marks the slots it writes as its own again). */
+int mpx_input_planes(mpx_engine* h, void** hi, void** lo);
 /* DEV pointers of the pooled stem output planes: fp16 [max_batch][56][56][64], written by the stem + max pool launch of mpx_forward or by
  * mpx_stem_table_apply (NULL for the small networks, which have no such stem). */
 int mpx_stem_planes(const mpx_engine* h, void** hi, void** lo);

@@ -9,7 +9,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpx.so")
+# MPX_LIB_PATH: another build of the library for this process AND the processes it starts (tools/with_lib.py sets it for a probe
+# build, so that `bench.py --gpus N`'s child ranks bind what the parent was told to bind); unset = the product library in the tree
+LIB_PATH = os.environ.get("MPX_LIB_PATH") or os.path.join(_HERE, "libmpx.so")
 
 IMG = 224
 IMG_PAD = 230

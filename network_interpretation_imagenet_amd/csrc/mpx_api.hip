@@ -1808,10 +1808,14 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
     return 0;
 }
 
-int mpx_input_planes(const mpx_engine* h, void** hi, void** lo) {
+int mpx_input_planes(mpx_engine* h, void** hi, void** lo) {
     if (!h || !hi || !lo) return MPX_E_ARG;
     *hi = h->in_hi;
     *lo = h->in_lo;
+    // whoever asks for these pointers may write the staging by hand: from here on every slot counts as staged THROUGH the input planes
+    // (the next forward runs the stem conv on them) until mpx_stem_table_apply marks slots as its own again -- a forward must never skip
+    // the stem over planes a caller has just written because an earlier batch of those slots came from the table
+    std::fill(h->slot_src.begin(), h->slot_src.end(), (uint8_t)1);
     return 0;
 }
 

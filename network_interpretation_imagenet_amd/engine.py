@@ -137,6 +137,24 @@ class MaskedForwardEngine:
             raise ValueError("%s has no 7x7 stem: stem='table' is the ImageNet ResNets' path" % arch)
         self.stem = "conv" if self.small else (stem or "table")
 
+    def stem_for_rows(self, rows_per_image):
+        """The staging a JOB of `rows_per_image` mask rows per image gets on this engine: "table" (the stem by superposition) from
+        `stem_table_min_rows` rows on, "conv" (K0 + the MFMA stem) below or when the engine was created with stem="conv".  The two stagings
+        round differently (<= 2.5e-6 on a score), so whoever SPLITS a job -- shard.score_masks_sharded / heatmap_sharded over ranks, a caller
+        cutting an image's rows into several calls -- decides ONCE from the job's row count with this function and hands the answer to
+        every call as `stem=`: the shards then carry the bits of the unsplit call."""
+        return "table" if (self.stem == "table" and int(rows_per_image) >= self.stem_table_min_rows) else "conv"
+
+    def _staging(self, stem, rows, images=1):
+        """Resolve a call's `stem=` argument: None = decide from the call's own rows per image (stem_for_rows), else the caller's choice."""
+        if stem is None:
+            return self.stem_for_rows(rows // max(1, images))
+        if stem not in ("table", "conv"):
+            raise ValueError("stem must be None, 'table' or 'conv', got %r" % (stem,))
+        if stem == "table" and self.small:
+            raise ValueError("%s has no 7x7 stem: stem='table' is the ImageNet ResNets' path" % self.arch)
+        return stem
+
     # ---- life cycle ----
     def close(self):
         if getattr(self, "_h", None):
@@ -380,11 +398,12 @@ class MaskedForwardEngine:
             res += (inputs,)
         return res
 
-    def score_masks(self, image, segments, onoff, label, return_logits=False):
+    def score_masks(self, image, segments, onoff, label, return_logits=False, stem=None):
         """(image, segments, onoff u8[M,S], label) -> (onoff u8[M,S], score f32[M], pred i32[M]).
         score[m] = softmax(model(normalised_image * mask_m))[label]
         (bayesian_active_learning_imagenet.py:187-198); pred[m] == label is the generators' binary
-        label (generate_gp_training_data_imagenet.py:248,257)."""
+        label (generate_gp_training_data_imagenet.py:248,257).  stem: None = staged by this call's row count (stem_for_rows(M)); "table" /
+        "conv" = the caller's choice -- a caller that scores PART of an image's rows passes stem_for_rows(all of them)."""
         if self.small:
             raise ValueError("%s scores with score_masks_removed (the small networks' mask convention)" % self.arch)
         seg_rank, s = rank_segments(segments)
@@ -397,7 +416,7 @@ class MaskedForwardEngine:
         m = onoff.shape[0]
         if not return_logits:
             # one upload, forwards of max_batch slots back to back, ONE download at the end (no per-chunk synchronisation)
-            score, pred = self.score_images([image], [seg_rank], [onoff], [label])[0]
+            score, pred = self.score_images([image], [seg_rank], [onoff], [label], stem=stem)[0]
             return onoff, score, pred
         score = np.empty(m, dtype=np.float32)
         pred = np.empty(m, dtype=np.int32)
@@ -407,10 +426,11 @@ class MaskedForwardEngine:
         img_d = self._image_to_device(image)
         seg_d = torch.from_numpy(seg_rank).to(self.device)
         onoff_d = torch.from_numpy(onoff).to(self.device)
+        table = self._staging(stem, m) == "table"
         for s0 in range(0, m, self.max_batch):
             b = min(self.max_batch, m - s0)
             labels = torch.full((b,), int(label), dtype=torch.int32, device=self.device)
-            if self.stem == "table" and m >= self.stem_table_min_rows:
+            if table:
                 if s0 == 0:
                     self.build_stem_table(img_d, seg_d, s)
                 self.apply_stem_table(onoff_d[s0:s0 + b], 0)
@@ -423,15 +443,18 @@ class MaskedForwardEngine:
                 logits[s0:s0 + b] = out[2].cpu().numpy()
         return (onoff, score, pred, logits) if return_logits else (onoff, score, pred)
 
-    def score_packed(self, images, segs, onoffs, label_rows, score_out, pred_out):
+    def score_packed(self, images, segs, onoffs, label_rows, score_out, pred_out, stem=None):
         """Device-resident packed scoring: the mask rows of SEVERAL images share forward batches of up to max_batch slots
         (an image's rows may straddle two batches), so the network always runs at the batch size it is fast at -- the
         reference scores one mask per forward (generate_gp_training_data_imagenet.py:240-248,
         gp_superpixel_data_imagenet.py:299-307).  images: sequence of device tensors (u8[224,224,3] or f32[3,224,224]);
         segs: ONE device i32[224,224] rank map shared by all images, or a sequence with one per image; onoffs: sequence of
         device u8[M_i, S_i]; label_rows: device i32[sum M_i] (image i's label repeated M_i times); score_out f32 / pred_out
-        i32 [sum M_i] receive the results.  Allocates nothing, synchronises nothing; results are bit-identical to scoring
-        every image on its own (kernel choice does not depend on where a mask sits in a batch)."""
+        i32 [sum M_i] receive the results.  Allocates nothing, synchronises nothing.  ONE kind of staging per call (a forward takes its slots
+        from one of the two): `stem` = "table" / "conv", or None = the table when the call brings at least stem_table_min_rows rows per image
+        with rows ON AVERAGE (stem_for_rows).  Within one staging a row's bits depend neither on where it sits in a batch nor on what else the
+        call scores (kernel choice does not depend on the position of a mask): results are bit-identical to scoring every image on its own
+        with the same `stem`."""
         n = len(images)
         shared = isinstance(segs, torch.Tensor)
         if len(onoffs) != n or (not shared and len(segs) != n):
@@ -443,8 +466,7 @@ class MaskedForwardEngine:
         label_rows, score_out, pred_out = label_rows.view(-1), score_out.view(-1), pred_out.view(-1)
         done = 0            # rows already handed to a forward
         used = 0            # slots staged for the next forward
-        # one kind of staging per call (a forward takes its slots from ONE of the two): the table when the images bring enough rows each
-        table = self.stem == "table" and total >= self.stem_table_min_rows * max(1, sum(1 for o in onoffs if int(o.shape[0])))
+        table = self._staging(stem, total, sum(1 for o in onoffs if int(o.shape[0]))) == "table"
         for i in range(n):
             m, r = int(onoffs[i].shape[0]), 0
             seg = segs if shared else segs[i]
@@ -465,15 +487,16 @@ class MaskedForwardEngine:
         if used:
             self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
 
-    def score_images(self, images, segments, onoffs, labels):
+    def score_images(self, images, segments, onoffs, labels, stem=None):
         """Host convenience over score_packed: [(image, segments, onoff u8[M_i,S_i], label)] for several images ->
         [(score f32[M_i], pred i32[M_i])], with ONE upload of the inputs and ONE download of all scores.  `segments` are
-        arbitrary integer label maps (ranked here as score_masks does)."""
+        arbitrary integer label maps (ranked here as score_masks does); `stem` as in score_packed."""
         if self.small:
             raise ValueError("%s scores with score_masks_removed (the small networks' mask convention)" % self.arch)
         n = len(images)
         if not (len(segments) == len(onoffs) == len(labels) == n):
             raise ValueError("images, segments, onoffs and labels must have the same length")
+        self._staging(stem, 0)           # a bad `stem` fails here, whatever the rows
         img_d, seg_d, onoff_d, lab, sizes = [], [], [], [], []
         for i in range(n):
             seg_rank, s = rank_segments(segments[i])
@@ -495,7 +518,7 @@ class MaskedForwardEngine:
         label_rows = torch.from_numpy(np.concatenate(lab)).to(self.device)
         score = torch.empty(total, dtype=torch.float32, device=self.device)
         pred = torch.empty(total, dtype=torch.int32, device=self.device)
-        self.score_packed(img_d, seg_d, onoff_d, label_rows, score, pred)
+        self.score_packed(img_d, seg_d, onoff_d, label_rows, score, pred, stem=stem)
         score, pred = score.cpu().numpy(), pred.cpu().numpy()
         out, at = [], 0
         for m in sizes:
@@ -528,11 +551,12 @@ class MaskedForwardEngine:
                    "mpx_heatmap_accumulate")
         return heat
 
-    def heatmap_device(self, image, seg_rank, onoff, label, buf):
+    def heatmap_device(self, image, seg_rank, onoff, label, buf, stem=None):
         """Score the M mask-vectors of one image and accumulate their heat map WITHOUT a host round trip:
         buf (device f32[224*224 + 1]) gets heat[p] += sum_m [pred[m] == label] * onoff[m][seg[p]] in its first 224*224 elements
         (K5, gp_superpixel_data_imagenet.py:322-323) and the number of correctly predicted masks added to its last element --
-        the layout shard.heatmap_sharded closes with ONE all_reduce.  -> (score f32[M], pred i32[M]) device tensors."""
+        the layout shard.heatmap_sharded closes with ONE all_reduce (which passes stem_for_rows(the image's rows over ALL ranks) as `stem`).
+        -> (score f32[M], pred i32[M]) device tensors."""
         if buf.dtype != torch.float32 or buf.device != self.device or buf.numel() != IMG * IMG + 1 or not buf.is_contiguous():
             raise ValueError("buf must be a contiguous float32[%d] tensor on %s" % (IMG * IMG + 1, self.device))
         seg_rank, s = rank_segments(seg_rank)               # a rank map passes through on the histogram's fast path
@@ -542,6 +566,7 @@ class MaskedForwardEngine:
         if not 0 <= int(label) < NUM_CLASSES:
             raise ValueError("label %r outside [0,1000)" % (label,))
         m = int(onoff.shape[0])
+        self._staging(stem, m)
         score = torch.empty(m, dtype=torch.float32, device=self.device)
         pred = torch.empty(m, dtype=torch.int32, device=self.device)
         if m == 0:
@@ -549,7 +574,7 @@ class MaskedForwardEngine:
         seg_d = torch.from_numpy(seg_rank).to(self.device)
         onoff_d = torch.from_numpy(onoff).to(self.device)
         labels = torch.full((m,), int(label), dtype=torch.int32, device=self.device)
-        self.score_packed([self._image_to_device(image)], seg_d, [onoff_d], labels, score, pred)
+        self.score_packed([self._image_to_device(image)], seg_d, [onoff_d], labels, score, pred, stem=stem)
         self.heatmap_accumulate(seg_d, onoff_d, pred, labels, buf[:IMG * IMG].view(IMG, IMG))
         buf[IMG * IMG] += (pred == labels).sum()
         return score, pred

@@ -56,10 +56,20 @@ def all_gather_blocks(local, total, group=None):
     return torch.cat(parts)
 
 
+def job_stem(engine, rows_per_image):
+    """The staging of a JOB (engine.stem_for_rows): decided from the rows an image has over ALL ranks, never from the rows a rank, a
+    block or a call happens to hold -- the stem table and K0 + the MFMA stem round differently (<= 2.5e-6 on a score), so a choice made
+    per shard would give a 512-mask image the table on one GPU and K0 on eight.  None for engine stand-ins without the method."""
+    fn = getattr(engine, "stem_for_rows", None)
+    return fn(rows_per_image) if fn is not None else None
+
+
 def score_sharded(score_image_fn, num_images, masks_per_image, device, group=None):
     """score_image_fn(img, m_lo, m_hi) -> 1-D f32 tensor of m_hi-m_lo scores on `device`.
-    Runs this rank's block and returns all num_images*masks_per_image scores on every rank
-    (bit-identical to the 1-GPU result: same kernels, disjoint blocks)."""
+    Runs this rank's block and returns all num_images*masks_per_image scores on every rank.  A block can cut an image's rows in
+    two (its tail on rank r, its head on rank r + 1): for results bit-identical to the 1-GPU run `score_image_fn` must stage every piece
+    the way the WHOLE image would be staged -- engine.score_masks(..., stem=job_stem(engine, masks_per_image)); with that the blocks
+    run the same kernels on disjoint rows."""
     total = num_images * masks_per_image
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -75,7 +85,8 @@ def score_masks_sharded(engine, image, segments, onoff, label, group=None):
     """Single-image case (BASELINE config 5: one image, every candidate window of a BO round): shard the MASK
     axis, every rank holds the image.  Each rank scores its contiguous block of mask-vectors with its own engine
     and ONE all-gather returns the full (score f32[M], pred i32[M]) on every rank -- bit-identical to one engine
-    scoring all M (same kernels, disjoint blocks).  The scores travel as their bit patterns next to the predictions in one
+    scoring all M: the staging (stem table or K0 + the MFMA stem) is chosen from the GLOBAL row count M (job_stem) and handed to every
+    rank's call, so the blocks run the kernels the unsplit call runs, on disjoint rows.  The scores travel as their bit patterns next to the predictions in one
     i32[2 * width] buffer per rank ("one RCCL all_gather"); nothing is converted, so NaN payloads and signed
     zeros arrive as they left."""
     import numpy as np
@@ -85,7 +96,9 @@ def score_masks_sharded(engine, image, segments, onoff, label, group=None):
     else:
         rank, world = 0, 1
     lo, hi = block(m, rank, world)
-    _o, score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+    stem = job_stem(engine, m)
+    kw = {} if stem is None else {"stem": stem}
+    _o, score, pred = engine.score_masks(image, segments, onoff[lo:hi], label, **kw)
     score = np.ascontiguousarray(score, dtype=np.float32)
     pred = np.ascontiguousarray(pred, dtype=np.int32)
     if world == 1:
@@ -126,8 +139,10 @@ def heatmap_sharded(engine, image, segments, onoff, label, group=None):
     each rank scores its block and accumulates sum_m [pred[m] == label] * onoff[m][seg[p]] straight into a device buffer
     f32[224*224 + 1] (K5 through engine.heatmap_device: no host round trip) whose LAST element carries the rank's number of
     correctly predicted masks, and ONE all_reduce(SUM) of that buffer closes the image ("one all_reduce of
-    f32[224*224] per image"; the count rides along).  Equal to the single-engine map exactly: integer counts below 2^24, so the
-    f32 sum does not depend on the reduction order.  `segments` must be a rank map (engine.rank_segments).
+    f32[224*224] per image"; the count rides along).  Equal to the single-engine map exactly: every rank stages its block the way the
+    whole image's M rows would be staged (job_stem: the GLOBAL row count decides between the stem table and K0), so each mask's argmax is the
+    single engine's, and the sums are integer counts below 2^24 -- the f32 result does not depend on the reduction order.  `segments` must be
+    a rank map (engine.rank_segments).
     returns (heat f32[224,224] tensor on the engine's device, n_correct int over all ranks)."""
     import numpy as np
     m = int(onoff.shape[0])
@@ -141,9 +156,10 @@ def heatmap_sharded(engine, image, segments, onoff, label, group=None):
     buf = torch.zeros(HEAT_ELEMS + 1, dtype=torch.float32, device=device)
     if hi > lo:
         if hasattr(engine, "heatmap_device"):
-            engine.heatmap_device(image, segments, onoff[lo:hi], label, buf)
+            engine.heatmap_device(image, segments, onoff[lo:hi], label, buf, stem=job_stem(engine, m))
         else:                           # engine stand-ins of the CPU tests: host K5
-            _o, _score, pred = engine.score_masks(image, segments, onoff[lo:hi], label)
+            stem = job_stem(engine, m)
+            _o, _score, pred = engine.score_masks(image, segments, onoff[lo:hi], label, **({} if stem is None else {"stem": stem}))
             part = engine.heatmap(segments, onoff[lo:hi], pred, label)            # f64[224,224], exact
             buf[:HEAT_ELEMS] = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32).ravel())
             buf[HEAT_ELEMS] = float((np.asarray(pred) == label).sum())

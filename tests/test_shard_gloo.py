@@ -110,6 +110,52 @@ def test_mask_axis_sharding_single_image(tmp_path, m):
         assert got["collectives"].tolist() == [2 * (-(-m // 2))]            # one collective: score bits + preds of the widest block
 
 
+class _StagingEngine(_TableEngine):
+    """Stand-in that has the engine's staging rule (stem_for_rows, threshold 256) and records the `stem` every call was handed."""
+    stem_table_min_rows = 256
+
+    def __init__(self):
+        self.seen = []
+
+    def stem_for_rows(self, rows):
+        return "table" if rows >= self.stem_table_min_rows else "conv"
+
+    def score_masks(self, image, segments, onoff, label, stem=None):
+        self.seen.append((int(onoff.shape[0]), stem))
+        return _TableEngine.score_masks(self, image, segments, onoff, label)
+
+
+def _staging_worker(rank, world, port, m, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        onoff = (np.random.default_rng(5).random((m, 23)) < 0.4).astype(np.uint8)
+        eng = _StagingEngine()
+        shard.score_masks_sharded(eng, None, None, onoff, 0)
+        shard.heatmap_sharded(eng, None, _seg23(), onoff, 3)
+        with open(os.path.join(out_dir, "s%d.txt" % rank), "w") as fh:
+            fh.write(repr(eng.seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m,want", [(400, "table"), (512, "table"), (255, "conv"), (40, "conv")])
+def test_staging_is_chosen_from_the_global_row_count(tmp_path, m, want):
+    """SURVEY 8(e) "bit-identical to the 1-GPU run": the stem table and K0 + the MFMA stem round differently, so the choice must not
+    depend on how many rows a rank holds.  400 rows are table-staged on one engine; two ranks of 200 (< 256 each) must be handed
+    stem="table" too -- and 255 rows stay on "conv" however they are cut."""
+    mp.spawn(_staging_worker, args=(2, _free_port(), m, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        seen = eval(open(tmp_path / ("s%d.txt" % r)).read())
+        lo, hi = shard.block(m, r, 2)
+        assert seen == [(hi - lo, want), (hi - lo, want)]           # the mask-axis split and the heat map's scoring call
+    single = _StagingEngine()
+    shard.score_masks_sharded(single, None, None, (np.random.default_rng(5).random((m, 23)) < 0.4).astype(np.uint8), 0)
+    assert single.seen == [(m, want)]
+    assert shard.job_stem(_TableEngine(), 400) is None                # stand-ins without the rule are called without `stem`
+
+
 def _seg23():
     idx = np.arange(224) // 10
     return ((idx[:, None] + idx[None, :]) % 23).astype(np.int32)

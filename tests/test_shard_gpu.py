@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 N_IMG, N_MASK, S = 3, 37, 64
+N_WIDE = 400        # one image's rows in the wide case: >= stem_table_min_rows (256) as a whole, 200 < 256 per rank
 
 
 def _inputs():
@@ -21,6 +22,11 @@ def _inputs():
     seg = synth.grid_segments(block=28)
     onoff = [synth.random_onoff(N_MASK, S, seed=90 + i) for i in range(N_IMG)]
     return imgs, seg, onoff
+
+
+def _wide():
+    from network_interpretation_imagenet_amd import synth
+    return synth.random_onoff(N_WIDE, S, seed=321)
 
 
 def _free_port():
@@ -46,9 +52,16 @@ def _worker(rank, world, port, out_dir):
         heat, n_ok = shard.heatmap_sharded(eng, imgs[1], seg, onoff[1], int(pred[0]))
         # cfg-4 shape: the flat (image, mask) range cut image-first, one all-gather of the scores
         def fn(i, lo, hi):
-            return torch.from_numpy(eng.score_masks(imgs[i], seg, onoff[i][lo:hi], 5)[1])
+            return torch.from_numpy(eng.score_masks(imgs[i], seg, onoff[i][lo:hi], 5, stem=shard.job_stem(eng, N_MASK))[1])
         flat = shard.score_sharded(fn, N_IMG, N_MASK, torch.device("cpu"))
-        np.savez(os.path.join(out_dir, "g%d.npz" % rank), score=score, pred=pred, heat=heat.cpu().numpy(), n_ok=n_ok, flat=flat.numpy())
+        # the staging is a property of the JOB: 400 rows of one image are table-staged as a whole, and so must the 200 of each rank be
+        # (a per-call choice gave the shards K0 + the MFMA stem, 2.5e-6 away from the single engine)
+        wide = _wide()
+        assert shard.job_stem(eng, N_WIDE) == "table" and eng.stem_for_rows(N_WIDE // world) == "conv"
+        w_score, w_pred = shard.score_masks_sharded(eng, imgs[2], seg, wide, 5)
+        w_heat, w_ok = shard.heatmap_sharded(eng, imgs[2], seg, wide, int(w_pred[0]))
+        np.savez(os.path.join(out_dir, "g%d.npz" % rank), score=score, pred=pred, heat=heat.cpu().numpy(), n_ok=n_ok, flat=flat.numpy(),
+                 w_score=w_score, w_pred=w_pred, w_heat=w_heat.cpu().numpy(), w_ok=w_ok)
         eng.close()
     finally:
         dist.destroy_process_group()
@@ -66,6 +79,12 @@ def test_two_engine_processes_shard_like_one(tmp_path, mpx_lib):
         _o, _s, p1 = eng.score_masks(imgs[1], seg, onoff[1], label)
         want_heat = eng.heatmap(seg, onoff[1], p1, label)
         want_flat = np.concatenate([eng.score_masks(imgs[i], seg, onoff[i], 5)[1] for i in range(N_IMG)])
+        wide = _wide()
+        _o, want_ws, want_wp = eng.score_masks(imgs[2], seg, wide, 5)                  # 400 rows in one call: the stem table
+        w_label = int(want_wp[0])
+        _o, _s, wp1 = eng.score_masks(imgs[2], seg, wide, w_label)
+        want_wheat = eng.heatmap(seg, wide, wp1, w_label)
+        _o, k0_ws, _p = eng.score_masks(imgs[2], seg, wide, 5, stem="conv")            # the other staging: close, not equal
     finally:
         eng.close()
     for r in range(2):
@@ -73,3 +92,7 @@ def test_two_engine_processes_shard_like_one(tmp_path, mpx_lib):
         assert np.array_equal(got["score"], want_s) and np.array_equal(got["pred"], want_p)            # bit-identical on every rank
         assert np.array_equal(got["heat"].astype(np.float64), want_heat) and int(got["n_ok"]) == int((p1 == label).sum())
         assert np.array_equal(got["flat"], want_flat)
+        assert np.array_equal(got["w_score"], want_ws) and np.array_equal(got["w_pred"], want_wp)
+        assert np.array_equal(got["w_heat"].astype(np.float64), want_wheat) and int(got["w_ok"]) == int((wp1 == w_label).sum())
+    # the comparison above has teeth: the two stagings do differ in bits on these rows (and agree within the engine's tolerance)
+    assert not np.array_equal(k0_ws, want_ws) and float(np.abs(k0_ws - want_ws).max()) <= 2e-5

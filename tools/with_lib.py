@@ -19,6 +19,7 @@ if not os.path.exists(lib):
 from network_interpretation_imagenet_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = lib
+os.environ["MPX_LIB_PATH"] = lib         # child processes (bench.py --gpus N starts its own ranks) bind the same file
 sys.stderr.write("with_lib: this process binds %s (NOT the product library)\n" % lib)
 sys.argv = [script] + sys.argv[3:]
 runpy.run_path(script, run_name="__main__")
