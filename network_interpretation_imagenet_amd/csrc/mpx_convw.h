@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         const int rec = rem > 0x7fffffffLL ? 0x7fffffff : (rem < 0 ? 0 : (int)rem);
         x_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x_hi + (size_t)m0 * K), 0, rec, 0x00020000);
         x_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x_lo + (size_t)m0 * K), 0, rec, 0x00020000);
-        x_dead = ti < my_tiles ? 0 : (int)OOB;          // past the last tile: the pieces are still issued, but touch no memory
+        x_dead = (ti < my_tiles && !(MPX_ABL_LO8 & 128)) ? 0 : (int)OOB;          // past the last tile: the pieces are still issued, but touch no memory
     };
     auto dma_stage = [&](int buf, int ks) {     // this wave's two pieces of stage ks of the tile being fetched
         char* d = smem + buf * C::TILE + ks * C::STAGE + wave * 1024;
@@ -188,8 +188,12 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                rh[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, offA[b] + k * row8, 0, 2);
-                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, offA[b] + k * row8, 0, 2);
+                rh[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, (offA[b] + k * row8) | ((MPX_ABL_LO8 & 128) ? (int)OOB : 0), 0, 2);
+                if (MPX_ABL_LO8 & 1) {          // timing-only: 8 B of the lo plane per lane
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r_lo_rs, (offA[b] + k * row8) >> 1, 0, 2);
+                    rl[b][k] = u4{t[0], t[1], 0u, 0u};
+                } else
+                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, (offA[b] + k * row8) | ((((MPX_ABL_LO8 & 16) && k) || (MPX_ABL_LO8 & 128)) ? (int)OOB : 0), 0, 2);
             }
     };
     auto epilogue = [&](int ti, auto&& after_slice) {               // 16 stores
@@ -251,8 +255,12 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                __builtin_amdgcn_raw_buffer_store_b128(so_h[b][k], y_hi_rs, offA[b] + k * row8, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(so_l[b][k], y_lo_rs, offA[b] + k * row8, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(so_h[b][k], y_hi_rs, (offA[b] + k * row8) | ((MPX_ABL_LO8 & 128) ? (int)OOB : 0), 0, 2);
+                if (MPX_ABL_LO8 & 1) {
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u2{so_l[b][k][0], so_l[b][k][1]}, y_lo_rs, (offA[b] + k * row8) >> 1, 0, 2);
+                } else
+                __builtin_amdgcn_raw_buffer_store_b128(so_l[b][k], y_lo_rs, (offA[b] + k * row8) | ((((MPX_ABL_LO8 & 16) && k) || (MPX_ABL_LO8 & 128)) ? (int)OOB : 0), 0, 2);
             }
     };
 

@@ -1059,20 +1059,35 @@ def test_cfg2_resnet18_256_masks_per_image_in_one_batch(mpx_lib, dev):
         small.close()
 
 
-def test_cfg5_bo_window_sweep_on_hip_engine_vs_oracle_loop(mpx_lib, dev, golden_dir):
+def _cfg5_case(kind, golden_dir):
+    """(u8 picture, label map as the segmentation library returned it): the felzenszwalb fixture (what the reference's scorers call),
+    or one of the two SLIC maps of tests/golden/segments_slic.npz (what BASELINE configs[4] names; generate_superpixels.py:2 imports
+    slic) -- "slic1" carries labels 1 .. S, a map that does not start at 0."""
+    if kind == "felzenszwalb":
+        g = np.load(os.path.join(golden_dir, "felzenszwalb_skimage0183.npz"))
+        return g["blobs224/image"], g["blobs224/labels"].astype(np.int64)
+    g = np.load(os.path.join(golden_dir, "segments_slic.npz"))
+    i = int(kind[-1])
+    return synth.make_images(2, seed=int(g["image_seed"]), kind="blobs")[i], g["segments"][i].astype(np.int64)
+
+
+@pytest.mark.parametrize("kind", ["felzenszwalb", "slic0", "slic1"])
+def test_cfg5_bo_window_sweep_on_hip_engine_vs_oracle_loop(mpx_lib, dev, golden_dir, kind):
     """BASELINE configs[4] / SURVEY 8 f1: the reference-named BO objective on the HIP engine.  On the committed
-    felzenszwalb fixture (scikit-image 0.18.3 labels of the blobs224 picture) api.sample_loss([f], ...) for EVERY
+    felzenszwalb fixture (scikit-image 0.18.3 labels of the blobs224 picture) and on the two SLIC label maps (scikit-image 0.18.3,
+    labels from 0 and from 1) api.sample_loss([f], ...) for EVERY
     f in [0, int(0.6*S)] must agree with the oracle's literal loop (bayesian_active_learning_imagenet.py:173-198:
     np.unique(segments)[f:f+k] -> mask[segments == v] = 1 -> input*mask -> batch-1 forward -> softmax[label]);
     then bo.bayesian_optimisation runs end to end (BayesianOptimization.py:99-192 signature) and every y it
-    collected is the table entry of its x."""
+    collected is the table entry of its x.  The SLIC cases also put random on/off vectors through engine.score_masks against the
+    oracle loop (the generators' entry) with the label map exactly as the library returned it."""
     import random
     from network_interpretation_imagenet_amd import api, bo
     arch = "resnet101"
     sd = synth.make_state_dict(arch)
-    g = np.load(os.path.join(golden_dir, "felzenszwalb_skimage0183.npz"))
-    img, seg = g["blobs224/image"], g["blobs224/labels"].astype(np.int64)
+    img, seg = _cfg5_case(kind, golden_dir)
     S = len(np.unique(seg))
+    assert int(seg.min()) == (1 if kind == "slic1" else 0)
     ub = scorer.bo_upper_bound(S)
     x = scorer.to_tensor_normalize(img)
     label = scorer.base_prediction(sd, arch, x)
@@ -1096,6 +1111,11 @@ def test_cfg5_bo_window_sweep_on_hip_engine_vs_oracle_loop(mpx_lib, dev, golden_
         assert xp.shape == (13, 1) and yp.shape == (13,)
         assert ((xp >= 0) & (xp <= ub)).all()
         assert all(np.float32(y) == got[int(f)] for f, y in zip(xp[:, 0], yp))
+        if kind != "felzenszwalb":
+            onoff = synth.random_onoff(6, S, seed=17)
+            _o, g_score, g_pred = eng.score_masks(img, seg, onoff, label)              # raw labels in, ranked inside (np.unique order)
+            w_score, w_pred = scorer.score_masks_reference_loop(sd, arch, x, seg, onoff, label)
+            assert float(np.abs(g_score - w_score).max()) <= SCORE_TOL_TIGHT and (g_pred == w_pred).all()
     finally:
         api.configure(eval_img_index=1, segmenter=None, mask_dir=None, seed=None)
         eng.close()

@@ -44,3 +44,18 @@ def test_shard_blocks_partition_the_range(total, world, per_image):
         assert all(0 <= m_lo < m_hi <= per_image for _i, m_lo, m_hi in pieces)
         covered += flat
     assert covered == list(range(total))
+
+
+def test_slic_label_maps_rank_like_np_unique():
+    """BASELINE configs[4] names SLIC label maps (generate_superpixels.py:2): the two committed scikit-image 0.18.3 maps -- labels 0 .. 89
+    and labels 1 .. 94 (a map that does not start at 0) -- rank like np.unique, and every window of the BO domain expands to the pixel mask
+    the reference's literal loop builds (bayesian_active_learning_imagenet.py:173-185)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "segments_slic.npz"))
+    assert [int(s.min()) for s in g["segments"]] == [0, 1]
+    for seg in g["segments"].astype(np.int64):
+        rank, s = rank_segments(seg)
+        uniq = np.unique(seg)
+        assert s == len(uniq) and rank.dtype == np.int32 and (uniq[rank] == seg).all()
+        for f in (0, 1, s // 3, masks.bo_upper_bound(s)):
+            assert (masks.expand_pixel_mask(rank, masks.window_onoff(s, f)) == scorer.window_mask_u8(seg, f)).all()
