@@ -168,7 +168,10 @@ int mpx_mask_apply_normalize(mpx_engine* h, const uint8_t* img_u8_hwc, const flo
  *           one of u8 HWC / f32 CHW; seg ranks in [0, S); onoff[m][s] != 0 keeps superpixel s), S <= 4096.  fp32 FMA chains in tap
  *           order instead of the MFMA stem's split-fp16 products: equal up to rounding (~1e-7 relative).
  * mpx_forward runs the B slots from the pooled planes when ALL of them were staged this way since they were last staged by
- * mpx_mask_apply_normalize, from the input staging when none was, and fails (MPX_E_STATE) on a mixed batch. */
+ * mpx_mask_apply_normalize, from the input staging when none was, and fails (MPX_E_STATE) on a mixed batch.
+ * The table's device memory (160 MB, independent of max_batch) is allocated by the FIRST mpx_stem_table_build of an engine -- the one
+ * allocation behind this boundary after mpx_create (an engine that only stages through mpx_mask_apply_normalize never holds it);
+ * mpx_workspace_bytes includes it from then on, mpx_destroy frees it. */
 int mpx_stem_table_build(mpx_engine* h, const uint8_t* img_u8_hwc, const float* img_f32_chw, const int32_t* seg, int S,
                          const float mean[3], const float std[3], void* stream);
 int mpx_stem_table_apply(mpx_engine* h, const uint8_t* onoff, int M, int S, int slot0, void* stream);

@@ -116,6 +116,8 @@ struct mpx_engine {
     bool fuse_bt = true;            // mpx_forward uses ops_bt when every tail is ready (mpx_set_fusion bit 1)
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    char* tab_arena = nullptr;      // the stem table of one image (CSR, heavy-pixel list, bit planes): allocated by the FIRST mpx_stem_table_build
+    size_t tab_arena_bytes = 0;
     half_t* in_hi = nullptr;
     half_t* in_lo = nullptr;
     half_t* act_hi[kActBufs] = {};
@@ -137,6 +139,7 @@ struct mpx_engine {
     int* tab_heavy = nullptr;       // [56 * 56 + 1]: the heavy pooled pixels of the table in place, last element = their number
     float* tab_vec = nullptr;
     unsigned* tab_bits = nullptr;   // [4096][ceil(max_batch / 32) + 1]
+    size_t tab_sizes[4] = {0, 0, 0, 0};   // bytes of one int vector / lab / vec / bits (mpx_create), taken from tab_arena on first use
     int tab_S = -1;                 // S of the table in place (-1: none)
     bool stem_w_loaded = false;
     std::vector<uint8_t> slot_src;  // per input slot: 0 = never staged, 1 = K0 (input staging), 2 = stem table (pooled planes)
@@ -1186,7 +1189,10 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     const size_t tab_lab_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * 4, 256) : 0;
     const size_t tab_vec_bytes = stemtab ? round_up((size_t)ST_MAX_ENTRIES * ST_C * 4, 256) : 0;
     const size_t tab_bits_bytes = stemtab ? round_up((size_t)4096 * tab_nmb * 4, 256) : 0;
-    const size_t stemtab_bytes = 2 * stem_plane + stem_w_bytes + 3 * tab_int_bytes + tab_lab_bytes + tab_vec_bytes + tab_bits_bytes;
+    // (the table itself -- 3 * tab_int + tab_lab + tab_vec + tab_bits, 160 MB -- is allocated by the first mpx_stem_table_build: an engine that
+    // only ever stages through K0, stem = "conv", never pays for it)
+    const size_t stemtab_bytes = 2 * stem_plane + stem_w_bytes;
+    h->tab_sizes[0] = tab_int_bytes; h->tab_sizes[1] = tab_lab_bytes; h->tab_sizes[2] = tab_vec_bytes; h->tab_sizes[3] = tab_bits_bytes;
     const size_t total = scratch_bytes + 2 * in_plane + 2 * kActBufs * act_plane + 2 * pool_plane + logit_bytes + k0_bytes + wbytes + stemtab_bytes;
     e = hipMalloc((void**)&h->arena, total);
     if (e != hipSuccess) { delete h; return (int)e; }
@@ -1210,12 +1216,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         h->stem_w32 = (float*)take(stem_w_bytes - 512);
         h->stem_s32 = (float*)take(256);
         h->stem_t32 = (float*)take(256);
-        h->tab_cnt = (int*)take(tab_int_bytes);
-        h->tab_off = (int*)take(tab_int_bytes);
-        h->tab_heavy = (int*)take(tab_int_bytes);
-        h->tab_lab = (int*)take(tab_lab_bytes);
-        h->tab_vec = (float*)take(tab_vec_bytes);
-        h->tab_bits = (unsigned*)take(tab_bits_bytes);
     }
     h->slot_src.assign((size_t)max_batch, 0);
     for (ConvLayer& L : h->convs) {
@@ -1312,6 +1312,7 @@ int mpx_destroy(mpx_engine* h) {
         (void)hipEventDestroy(r.t1);
     }
     if (h->arena) (void)hipFree(h->arena);
+    if (h->tab_arena) (void)hipFree(h->tab_arena);
     delete h;
     return 0;
 }
@@ -1320,7 +1321,7 @@ const char* mpx_last_error(const mpx_engine* h) { return h ? h->err.c_str() : "n
 int mpx_max_batch(const mpx_engine* h) { return h ? h->max_batch : MPX_E_ARG; }
 int mpx_num_cus(const mpx_engine* h) { return h ? h->num_cus : MPX_E_ARG; }
 int mpx_last_conv_kernels(const mpx_engine* h) { return h ? (int)h->last_kernels : MPX_E_ARG; }
-size_t mpx_workspace_bytes(const mpx_engine* h) { return h ? h->arena_bytes : 0; }
+size_t mpx_workspace_bytes(const mpx_engine* h) { return h ? h->arena_bytes + h->tab_arena_bytes : 0; }
 int mpx_num_convs(const mpx_engine* h) { return h ? (int)h->convs.size() : MPX_E_ARG; }
 
 int mpx_conv_info(const mpx_engine* h, int i, mpx_conv_desc* out) {
@@ -1472,6 +1473,20 @@ int mpx_stem_table_build(mpx_engine* h, const uint8_t* img_u8_hwc, const float* 
     if (!seg || S <= 0 || S > 4096) return fail(h, MPX_E_ARG, "stem_table_build: null label map or S outside [1, 4096]");
     if (img_u8_hwc && (!mean || !std)) return fail(h, MPX_E_ARG, "stem_table_build: mean/std required for u8 input");
     if (!h->stem_w_loaded) return fail(h, MPX_E_STATE, "stem_table_build: layer 0 (%s) has no weights", h->convs[0].d.name);
+    MPX_SET_DEVICE(h);
+    if (!h->tab_arena) {            // first table of this engine: its 160 MB are allocated now, once (the only allocation behind the boundary after mpx_create)
+        const size_t total = 3 * h->tab_sizes[0] + h->tab_sizes[1] + h->tab_sizes[2] + h->tab_sizes[3];
+        MPX_HIP(h, hipMalloc((void**)&h->tab_arena, total));
+        h->tab_arena_bytes = total;
+        char* cur = h->tab_arena;
+        auto take = [&](size_t n) { char* r = cur; cur += n; return r; };
+        h->tab_cnt = (int*)take(h->tab_sizes[0]);
+        h->tab_off = (int*)take(h->tab_sizes[0]);
+        h->tab_heavy = (int*)take(h->tab_sizes[0]);
+        h->tab_lab = (int*)take(h->tab_sizes[1]);
+        h->tab_vec = (float*)take(h->tab_sizes[2]);
+        h->tab_bits = (unsigned*)take(h->tab_sizes[3]);
+    }
     StemTabParams p;
     std::memset(&p, 0, sizeof p);
     p.img_u8 = img_u8_hwc; p.img_f32 = img_f32_chw; p.seg = seg; p.S = S;

@@ -213,6 +213,17 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
+            if (MPX_ABL_LO8 & 512) {            // timing-only: no epilogue arithmetic
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        so_h[b][k][q] = __float_as_uint(acc[k][b][q]) ^ rh[b][k][q];
+                        so_l[b][k][q] = __float_as_uint(acc[2 + k][b][q]) ^ rl[b][k][q];
+                    }
+                after_slice(b);
+                continue;
+            }
             float ve[8], vo[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -182,6 +182,15 @@ def test_table_stem_engine_vs_conv_stem_engine_vs_cpu_loop(mpx_lib, arch, tight)
         assert worst <= tight and (p_t[:12] == ref_pred).all()
         _o, s_l, _p2, lg = tab.score_masks(img, seg, onoff[:5], label, return_logits=True)      # the logits path stages the same way
         assert (s_l == s_t[:5]).all()
+        # the table's 160 MB belong to engines that use it: allocated by the first mpx_stem_table_build, never by a K0-only engine ...
+        assert 140e6 < tab.workspace_bytes - conv.workspace_bytes < 200e6
+        # ... and a call may ask for either staging whatever the engine's default is (shard.job_stem hands the job's choice to every rank)
+        _o, s_ct, p_ct = conv.score_masks(img, seg, onoff, label, stem="table")
+        _o, s_tc, p_tc = tab.score_masks(img, seg, onoff, label, stem="conv")
+        assert np.array_equal(s_ct, s_t) and np.array_equal(s_tc, s_c) and (p_ct == p_t).all() and (p_tc == p_c).all()
+        assert tab.workspace_bytes == conv.workspace_bytes
+        with pytest.raises(ValueError):
+            tab.score_masks(img, seg, onoff, label, stem="mfma")
     finally:
         tab.close()
         conv.close()
