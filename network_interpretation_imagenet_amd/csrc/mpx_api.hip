@@ -8,7 +8,6 @@
 #include "mpx_conv256p.h"
 #include "mpx_convx.h"
 #include "mpx_convw.h"
-#include "mpx_convwc.h"
 #include "mpx_btail.h"
 #include "mpx_stemtab.h"
 #ifdef MPX_EXPERIMENTAL
@@ -613,13 +612,8 @@ int launch_convw(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     const int unit = 8 > p.n_tiles_c ? (8 % p.n_tiles_c == 0 ? 8 : 8 * p.n_tiles_c) : (p.n_tiles_c % 8 == 0 ? p.n_tiles_c : 8 * p.n_tiles_c);
     grid = grid / unit * unit;
     if (grid <= 0 || total < 2LL * h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
-#ifdef MPX_CONVW_COLMAJOR       // probe builds: the column-major form with the epilogue between the MFMAs (mpx_convwc.h)
-    if (p.relu) hipLaunchKernelGGL(convwc_f16x3_kernel<true>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
-    else hipLaunchKernelGGL(convwc_f16x3_kernel<false>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
-#else
     if (p.relu) hipLaunchKernelGGL(convw_f16x3_kernel<true>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
     else hipLaunchKernelGGL(convw_f16x3_kernel<false>, dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
-#endif
     MPX_HIP(h, hipGetLastError());
     h->last_kernels |= 1u << 14;
     return 0;
@@ -1271,12 +1265,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
         e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
-#ifdef MPX_CONVW_COLMAJOR
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convwc_f16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convwc_f16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
-#endif
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv256p_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256P::LDS);
     if (e == hipSuccess)

@@ -372,11 +372,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
             for (int u = 0; u < 4; ++u) {
                 const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 2) ? (int)OOB : 0);
                 idh[u] = __builtin_amdgcn_raw_buffer_load_b128(rh_rs, voff, c * 128, BT_AUX_LOAD);
-                if ((MPX_ABL_LO8 & 4) && !DUAL) {       // timing-only: 8 B of the lo plane per lane
-                    const auto t = __builtin_amdgcn_raw_buffer_load_b64(rl_rs, voff >> 1, c * 64, BT_AUX_LOAD);
-                    idl[u] = u4{t[0], t[1], 0u, 0u};
-                } else
-                idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff | (((MPX_ABL_LO8 & 32) && !DUAL && (u & 1)) ? (int)OOB : 0), c * 128, BT_AUX_LOAD);
+                idl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, voff, c * 128, BT_AUX_LOAD);
             }
         };
         auto read_a1 = [&](int slot, FragA& f, int i) {        // fragment read i = 0..7 of a stage: hi rows 0..3, lo rows 0..3
@@ -408,8 +404,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
 #pragma unroll
             for (int i = 0; i < 24; ++i) {
                 const int a = i / 6, r = i % 6, term = r >> 1, b = r & 1;
-                if ((MPX_ABL_LO8 & 256) && (i & 7) == 7) {}          // timing-only: 21 of the step's 24 MFMAs
-                else if (term == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], bl[b], acc[a][b], 0, 0, 0);
+                if (term == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], bl[b], acc[a][b], 0, 0, 0);
                 else if (term == 1) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo[a], bh[b], acc[a][b], 0, 0, 0);
                 else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi[a], bh[b], acc[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -655,12 +650,7 @@ __global__ __launch_bounds__(256, 2) void btail_f16x3_kernel(const BtParams p) {
                     bt_relu_split8(v, one, oh, ol);
                     const int voff = (u_pix[u] * (BT_OUT * 2) + uq * 16) | (u_pix[u] & (int)OOB) | ((BT_ABL & 4) ? (int)OOB : 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), yh, voff, c * 128, BT_AUX_STORE);
-                    if (MPX_ABL_LO8 & 4) {
-                        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                        const u4 t = __builtin_bit_cast(u4, ol);
-                        __builtin_amdgcn_raw_buffer_store_b64(u2{t[0], t[1]}, yl, voff >> 1, c * 64, BT_AUX_STORE);
-                    } else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff | (((MPX_ABL_LO8 & 32) && (u & 1)) ? (int)OOB : 0), c * 128, BT_AUX_STORE);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), yl, voff, c * 128, BT_AUX_STORE);
                     // operand layout for conv1': [fragment b][K step uq>>2][plane][16 slots][64 B], chunk uq&3 swizzled by the slot
                     char* const d = stg + (b * 4 + (uq >> 2) * 2) * 1024 + (slot & 15) * 64 + (((uq & 3) ^ (((slot >> 3) & 1) << 1)) << 4);
                     *(h8*)d = oh;

@@ -25,16 +25,6 @@
 #include <stdint.h>
 #include <type_traits>
 
-// TIMING-ONLY probe switch (never set in the product build; tools/ab_lo8.sh): prices a 3-byte activation format before anything is
-// built.  With bit k set, the `lo` plane traffic of one kernel class moves HALF its bytes -- same instruction count, wrong results:
-//   1  mpx_convw.h    residual lo loads and output lo stores are 8 B per lane instead of 16
-//   2  mpx_conv256p.h the X_lo pieces of odd K steps touch no memory (an 8-bit plane = one 1-KiB piece per two K steps)
-//   4  mpx_btail.h    identity lo loads and block-output lo stores are 8 B per lane
-//   8  mpx_convx.h    residual lo loads and output lo stores are 8 B per lane
-#ifndef MPX_ABL_LO8
-#define MPX_ABL_LO8 0
-#endif
-
 namespace mpx {
 
 typedef _Float16 half_t;

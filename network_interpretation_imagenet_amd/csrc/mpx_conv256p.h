@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv256p_f16x3_kernel(const ConvParams
             case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_hi, MPX_LDS_PTR(sb + C::OFF_WHI + d), 16, wvoff, wsoff, 0, 0); break;
             case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(w_lo, MPX_LDS_PTR(sb + C::OFF_WLO + d), 16, wvoff, wsoff, 0, 0); break;
             case 4: __builtin_amdgcn_raw_ptr_buffer_load_lds(x_hi, MPX_LDS_PTR(sb + C::OFF_XHI + d), 16, voff, soff, 0, 0); break;
-            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(x_lo, MPX_LDS_PTR(sb + C::OFF_XLO + d), 16, voff | (((MPX_ABL_LO8 & 2) && (f_ks & 1)) ? (int)OOB : 0), soff, 0, 0); break;
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(x_lo, MPX_LDS_PTR(sb + C::OFF_XLO + d), 16, voff, soff, 0, 0); break;
         }
     };
     auto next_fill = [&]() {                     // advance (f_tile, f_ks) after a stage has been issued

@@ -182,11 +182,7 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 rh[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, (offA[b] + k * row8) | ((CX_ABL & 4) ? (int)OOB : 0), 0, 2);
-                if (MPX_ABL_LO8 & 8) {          // timing-only: 8 B of the lo plane per lane
-                    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r_lo_rs, (offA[b] + k * row8) >> 1, 0, 2);
-                    rl[b][k] = u4{t[0], t[1], 0u, 0u};
-                } else
-                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, (offA[b] + k * row8) | (((CX_ABL & 4) || ((MPX_ABL_LO8 & 64) && k)) ? (int)OOB : 0), 0, 2);
+                rl[b][k] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, (offA[b] + k * row8) | ((CX_ABL & 4) ? (int)OOB : 0), 0, 2);
             }
     };
     auto epilogue = [&](int ti) {               // C::EPI_STORES stores
@@ -243,12 +239,7 @@ __global__ __launch_bounds__(512, 2) void convx_f16x3_kernel(const ConvParams p)
                     ol[j] = lo;
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, oh), y_hi_rs, (offA[b] + k * row8) | ((CX_ABL & 8) ? (int)OOB : 0), 0, 2);
-                if (MPX_ABL_LO8 & 8) {
-                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                    const u4 t = __builtin_bit_cast(u4, ol);
-                    __builtin_amdgcn_raw_buffer_store_b64(u2{t[0], t[1]}, y_lo_rs, (offA[b] + k * row8) >> 1, 0, 2);
-                } else
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, (offA[b] + k * row8) | (((CX_ABL & 8) || ((MPX_ABL_LO8 & 64) && k)) ? (int)OOB : 0), 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ol), y_lo_rs, (offA[b] + k * row8) | ((CX_ABL & 8) ? (int)OOB : 0), 0, 2);
             }
         }
     };
