@@ -106,34 +106,51 @@ __device__ __forceinline__ unsigned cw_pack_lo(unsigned hi, float one, float a, 
     return d;
 }
 
-struct ConvW {
+template <int KK>
+struct ConvWK {
+    static_assert(KK == 128 || KK == 256, "64 output channels x K x (hi + lo) must fit a wave's 256 AGPRs, and a column's MFMAs must cover an epilogue slice");
     static constexpr int TC = 256, TP = 64, NW = 4, NT = 256;
-    static constexpr int K = 256, NK = K / 32;
+    static constexpr int K = KK, NK = K / 32;
     static constexpr int STAGE = 8192;                  // one K step of the pixel tile: [X_hi 64 rows x 64 B | X_lo 64 rows x 64 B]
-    static constexpr int TILE = NK * STAGE;             // 64 KB
+    static constexpr int TILE = NK * STAGE;             // 64 KB (K = 256), 32 KB (K = 128)
     static constexpr int OFF_SCALE = 2 * TILE;          // f32[256] scale, f32[256] shift of the workgroup's cout tile
     static constexpr int LDS = 2 * TILE + 2048;
 };
+typedef ConvWK<256> ConvW;
 
+// Where a tile's memory instructions sit.  A column has NK * 12 MFMAs; the epilogue slice is written as 96 STAGES of one or two instructions
+// (K = 256: one stage per gap; K = 128: two), and every placement below is a stage number.
+template <int NK>
 struct ConvWC {
+    static constexpr int STAGES_PER_GAP = 96 / (NK * 12);
     static constexpr int DMA_COL = CWC_DMA_COL, DMA_NCOL = CWC_DMA_NCOL, DMA_GAP = CWC_DMA_GAP, RES_GAP = CWC_RES_GAP, RES_LEAD = CWC_RES_LEAD;
     static constexpr int ST_GAP0 = CWC_ST_GAP0, ST_GAP1 = CWC_ST_GAP1;
-    static constexpr int PAIRS_PER_COL = 8 / DMA_NCOL;                           // piece pairs (one K step of the tile) a requesting column issues
+    static constexpr int PAIRS_PER_COL = NK / DMA_NCOL;                          // piece pairs (one K step of the tile) a requesting column issues
     static constexpr int DMA_LAST_COL = DMA_COL + DMA_NCOL - 1, DMA_LAST_GAP = DMA_GAP + 2 * (PAIRS_PER_COL - 1);
     // memory instructions issued behind a tile's last piece: the rest of that column, then whole columns (4 loads + 4 stores each)
     static constexpr int TILE_END_WAIT = (RES_GAP > DMA_LAST_GAP ? 4 : 0) + (ST_GAP0 > DMA_LAST_GAP ? 2 : 0) + (ST_GAP1 > DMA_LAST_GAP ? 2 : 0) + (3 - DMA_LAST_COL) * 8;
-    static_assert(DMA_NCOL == 1 || DMA_NCOL == 2, "8 piece pairs over one or two columns");
+    static_assert(STAGES_PER_GAP * NK * 12 == 96, "whole stages per gap");
+    static_assert(DMA_NCOL == 1 || DMA_NCOL == 2, "the piece pairs of a tile over one or two columns");
     static_assert(DMA_LAST_COL <= 3 && DMA_LAST_GAP < 96 && RES_GAP + 3 < 96, "placements inside a column");
     static_assert(ST_GAP0 >= 40 && ST_GAP1 >= 65 && ST_GAP1 < 96 && ST_GAP0 <= ST_GAP1, "a half-slice is stored once its last value exists");
     static_assert(RES_LEAD >= 0 && RES_LEAD <= 2, "residual lines are requested one to three columns before their use");
     static_assert(TILE_END_WAIT <= 63, "vmcnt is six bits");
 };
 
-template <bool RELU>
+template <int N, class F>
+__device__ __forceinline__ void cw_static_for(F&& f) {          // f(integral_constant<0>), ..., f(integral_constant<N - 1>), in order
+    if constexpr (N > 0) {
+        cw_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int KK, bool RELU>
 __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef ConvW C;
+    typedef ConvWK<KK> C;
+    typedef ConvWC<KK / 32> W;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
     {
         const __amdgpu_buffer_rsrc_t r_hi_rs = plane_desc(p.r_hi, 0), r_lo_rs = plane_desc(p.r_hi ? p.r_lo : nullptr, 0);
 #pragma unroll
-        for (int s0 = 0; s0 < ConvWC::RES_LEAD; ++s0)        // the slices whose request would have fallen into the columns before tile 0
+        for (int s0 = 0; s0 < W::RES_LEAD; ++s0)        // the slices whose request would have fallen into the columns before tile 0
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 rh[s0][k] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, offA[s0] + k * row8, 0, 2);
@@ -274,21 +291,21 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
     // of the PREVIOUS column (SP = B - 1 of this tile; for B = 0 slice 3 of tile ti - 1) plus this column's share of the memory traffic.
     auto column = [&](auto b_tag, int ti, int buf) {
         constexpr int B = decltype(b_tag)::value;
-        constexpr int SP = (B + 3) & 3, SN = (B + ConvWC::RES_LEAD) & 3;
-        constexpr bool SN_NEXT_TILE = B + ConvWC::RES_LEAD > 3;
+        constexpr int SP = (B + 3) & 3, SN = (B + W::RES_LEAD) & 3;
+        constexpr bool SN_NEXT_TILE = B + W::RES_LEAD > 3;
         const __amdgpu_buffer_rsrc_t y_hi_rs = plane_desc(p.y_hi, B == 0 ? ti - 1 : ti), y_lo_rs = plane_desc(p.y_lo, B == 0 ? ti - 1 : ti);
         const __amdgpu_buffer_rsrc_t r_hi_rs = plane_desc(p.r_hi, SN_NEXT_TILE ? ti + 1 : ti);
         const __amdgpu_buffer_rsrc_t r_lo_rs = plane_desc(p.r_hi ? p.r_lo : nullptr, SN_NEXT_TILE ? ti + 1 : ti);
-        auto gap = [&](auto t_tag) {
+        auto stage = [&](auto t_tag) {
             constexpr int T = decltype(t_tag)::value;
             // ---- memory traffic of this column ----
-            if constexpr (T >= ConvWC::RES_GAP && T < ConvWC::RES_GAP + 4) {        // residual lines of slice SN: (k, plane) = (R >> 1, R & 1)
-                constexpr int R = T - ConvWC::RES_GAP;
+            if constexpr (T >= W::RES_GAP && T < W::RES_GAP + 4) {        // residual lines of slice SN: (k, plane) = (R >> 1, R & 1)
+                constexpr int R = T - W::RES_GAP;
                 if constexpr ((R & 1) == 0) rh[SN][R >> 1] = __builtin_amdgcn_raw_buffer_load_b128(r_hi_rs, offA[SN] + (R >> 1) * row8, 0, 2);
                 else rl[SN][R >> 1] = __builtin_amdgcn_raw_buffer_load_b128(r_lo_rs, offA[SN] + (R >> 1) * row8, 0, 2);
             }
-            if constexpr (B >= ConvWC::DMA_COL && B <= ConvWC::DMA_LAST_COL && T >= ConvWC::DMA_GAP && T <= ConvWC::DMA_LAST_GAP && ((T - ConvWC::DMA_GAP) & 1) == 0)
-                dma_stage(buf ^ 1, (B - ConvWC::DMA_COL) * ConvWC::PAIRS_PER_COL + ((T - ConvWC::DMA_GAP) >> 1));
+            if constexpr (B >= W::DMA_COL && B <= W::DMA_LAST_COL && T >= W::DMA_GAP && T <= W::DMA_LAST_GAP && ((T - W::DMA_GAP) & 1) == 0)
+                dma_stage(buf ^ 1, (B - W::DMA_COL) * W::PAIRS_PER_COL + ((T - W::DMA_GAP) >> 1));
             // ---- the epilogue slice SP, one or two instructions per gap (the first MFMAs of the column cover the distance to the last
             //      MFMA that wrote acc[.][SP]: the asm statements hide that hazard from hipcc) ----
             if constexpr (T >= 4 && T < 8) {
@@ -344,10 +361,10 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
             //  the counted vmcnt in front of the first use of each line; every memory instruction is issued on every pass -- dead ones with an
             //  out-of-range offset -- so the counts hold from the first tile on)
             if constexpr (T >= 20 && T < 40) qop(std::integral_constant<int, 0>{}, std::integral_constant<int, (T >= 20 && T < 40) ? T - 20 : 0>{});
-            if constexpr (T == ConvWC::ST_GAP0) store(std::integral_constant<int, 0>{});
+            if constexpr (T == W::ST_GAP0) store(std::integral_constant<int, 0>{});
             if constexpr (T >= 41 && T < 45) dpp(std::integral_constant<int, 1>{}, std::integral_constant<int, (T >= 41 && T < 45) ? T - 41 : 0>{});
             if constexpr (T >= 45 && T < 65) qop(std::integral_constant<int, 1>{}, std::integral_constant<int, (T >= 45 && T < 65) ? T - 45 : 0>{});
-            if constexpr (T == ConvWC::ST_GAP1) store(std::integral_constant<int, 1>{});
+            if constexpr (T == W::ST_GAP1) store(std::integral_constant<int, 1>{});
         };
         auto kstep = [&](auto ks_tag) {
             constexpr int ks = decltype(ks_tag)::value;
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                 } else if constexpr (term == 1) mfma_w(acc[a][B], wl[ks][a], fh[par]);
                 else mfma_w(acc[a][B], wh[ks][a], fh[par]);
                 __builtin_amdgcn_sched_barrier(0);
-                gap(std::integral_constant<int, ks * 12 + i>{});
+                cw_static_for<W::STAGES_PER_GAP>([&](auto r_tag) { stage(std::integral_constant<int, (ks * 12 + i) * W::STAGES_PER_GAP + decltype(r_tag)::value>{}); });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i == 1) {         // the next step's fragments: the other register pair, 10 MFMAs ahead of their first use
                     if constexpr (ks + 1 < NK) read_f(par ^ 1, buf, ks + 1, B);
@@ -369,14 +386,9 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            m(std::integral_constant<int, 0>{}); m(std::integral_constant<int, 1>{}); m(std::integral_constant<int, 2>{});
-            m(std::integral_constant<int, 3>{}); m(std::integral_constant<int, 4>{}); m(std::integral_constant<int, 5>{});
-            m(std::integral_constant<int, 6>{}); m(std::integral_constant<int, 7>{}); m(std::integral_constant<int, 8>{});
-            m(std::integral_constant<int, 9>{}); m(std::integral_constant<int, 10>{}); m(std::integral_constant<int, 11>{});
+            cw_static_for<12>(m);
         };
-        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
-        kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
-        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
+        cw_static_for<NK>(kstep);
     };
 
     int buf = 0;
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         // The next tile's 16 pieces were issued in columns 0 and 1; behind them: column 1's stores (4), columns 2 and 3 (4 loads + 4 stores
         // each).  Behind the barrier all four waves' pieces have landed and nobody reads this tile's buffer again.
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ConvWC::TILE_END_WAIT) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::TILE_END_WAIT) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         buf ^= 1;

@@ -257,11 +257,13 @@ def test_convx_persistent_expanding_kernel(eng101, name, batch):
 @pytest.mark.parametrize("name,batch", [("layer3.5.conv3", 47), ("layer3.5.conv3", 161), ("layer3.5.conv3", 5), ("layer3.22.conv3", 84),
                                         ("layer2.1.conv3", 25), ("layer3.5.conv1", 9)])
 def test_convw_weights_in_registers_kernel(eng101, name, batch):
-    """Tile id 14 = the persistent expanding-1x1 kernel whose weights live in registers (csrc/mpx_convw.h): K = 256 only (128 -> 512 and
-    1024 -> 256 are refused), 64-pixel tiles, one barrier per tile.  Batches give a ragged last tile (47 images = 143.9 pixel tiles,
-    161 = 493.06) and from 2 to 8 tiles per workgroup; 84 images are 257.25 pixel tiles: workgroups with 4 and with 5; under two rounds
-    of tiles (5 images) the launch runs on the 128x128 8-wave kernel.  Against the fp64 conv + BN + residual + ReLU, and bit-equal to
-    tile 10 (the same order of summation and the same epilogue arithmetic) -- the test asserts which kernel ran."""
+    """Tile id 14 = the persistent expanding-1x1 kernel whose weights live in registers (csrc/mpx_convw.h; since round 5 with a column-major
+    K loop and the epilogue slices between its MFMAs): K = 256 only (128 -> 512 and 1024 -> 256 are refused), 64-pixel tiles, one barrier per
+    tile.  Batches give a ragged last tile (47 images = 143.9 pixel tiles, 161 = 493.06) and from 2 to 8 tiles per workgroup; 84 images are
+    257.25 pixel tiles: workgroups with 4 and with 5; under two rounds of tiles (5 images) the launch runs on the 128x128 8-wave kernel.
+    (The kernel is a template over K; K = 128 was built, passed this test bit-equal to tile 10 and tied with it: not instantiated.)  Against the
+    fp64 conv + BN + residual + ReLU, and bit-equal to tile 10 (the same order of summation and the same epilogue arithmetic) -- the test
+    asserts which kernel ran."""
     i = _layer_index(eng101, name)
     d = eng101.layers[i]
     if not (d.cin == 256 and d.cout % 256 == 0 and d.ksize == 1):
