@@ -133,10 +133,14 @@ def test_conv_kernels_have_no_scratch_and_convw_keeps_its_weights_in_agprs(mpx_l
 
 
 def test_convw_k_loop_is_what_the_source_says():
-    """The three things hipcc did to the first builds of csrc/mpx_convw.h and the source now prevents, checked in the disassembly of the
-    built library: between the first and the last MFMA of the tile loop there is no v_accvgpr copy (the weights are MFMA operands IN the
-    AGPRs: inline asm with an "a" constraint), no s_waitcnt vmcnt (the weight loads are known to have returned: waitcnt builtin in the
-    prologue) and no scratch access; a tile is 8 K steps x 48 MFMAs, every one with an AGPR A operand."""
+    """What hipcc must (not) make of csrc/mpx_convw.h, checked in the disassembly of the built library.  Round 4: between the first and the
+    last MFMA of the tile loop there is no v_accvgpr copy (the weights are MFMA operands IN the AGPRs: inline asm with an "a" constraint)
+    and no scratch access; a tile is 8 K steps x 48 MFMAs, every one with an AGPR A operand.  Round 5 (column-major K loop, the epilogue
+    slices in the MFMA gaps): the MFMAs stay evenly spread -- no gap holds more than a handful of instructions, i.e. the epilogue was not
+    hoisted back into one block -- the residual loads, the pieces and the stores all sit INSIDE the loop, and every vmcnt in it is a
+    counted immediate that leaves instructions in flight (a vmcnt(0) would serialise the tile on its own stores; hipcc's own waits in front of
+    the residual lines' first uses are 14 .. 24, and it guards the first fragment read of a tile, whose registers it shares with the last
+    column's store data, with vmcnt(4) / vmcnt(5))."""
     import subprocess
     import tempfile
     objdump = os.path.join(LLVM_BIN, "llvm-objdump")
@@ -148,17 +152,28 @@ def test_convw_k_loop_is_what_the_source_says():
         fh.write(_device_elf(_lib.LIB_PATH))
         fh.flush()
         asm = subprocess.run([objdump, "-d", fh.name], capture_output=True, text=True, check=True).stdout
-    for relu in ("ILb1E", "ILb0E"):
-        m = re.search(r"<_ZN3mpx18convw_f16x3_kernel%sEEvNS_10ConvParamsE>:\n(.*?)\n\n" % relu, asm, re.S)
+    for relu in ("Lb1E", "Lb0E"):
+        m = re.search(r"<_ZN3mpx18convw_f16x3_kernelILi256E%sEEvNS_10ConvParamsE>:\n(.*?)\n\n" % relu, asm, re.S)
         assert m, "kernel not found in the disassembly"
         ins = [l.split("//")[0].strip() for l in m.group(1).splitlines()]
+        ins = [l for l in ins if l and not l.endswith(":")]
         mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f32_16x16x32_f16")]
         assert len(mf) == 384, len(mf)
         assert all(re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\]", ins[i]) for i in mf), "an MFMA without an AGPR A operand"
         loop = ins[mf[0]:mf[-1] + 1]
         assert not [l for l in loop if "v_accvgpr" in l], "AGPR copies in the K loop"
-        assert not [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l], "a vmcnt wait in the K loop"
         assert not [l for l in loop if l.startswith("scratch_")], "scratch access in the K loop"
+        # the column-major loop: stores, residual loads and LDS-DMA pieces between the MFMAs
+        n_store = len([l for l in loop if l.startswith("buffer_store_dwordx4")])
+        n_dma = len([l for l in loop if l.startswith("buffer_load_dwordx4") and l.endswith("lds")])
+        n_load = len([l for l in loop if l.startswith("buffer_load_dwordx4") and not l.endswith("lds")])
+        assert (n_store, n_load, n_dma) == (16, 16, 16), (n_store, n_load, n_dma)
+        waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert waits and min(waits) >= 4 and len(waits) <= 8, waits      # counted: traffic stays in flight behind every wait; none per MFMA gap
+        gaps = [b - a - 1 for a, b in zip(mf, mf[1:])]
+        # a gap holds one or two epilogue instructions, sometimes a fragment read or a memory instruction with its address arithmetic; the
+        # descriptor set-up of a column start and the tile end (wait, barrier, first fragment read) are the few long ones
+        assert sorted(gaps)[len(gaps) // 2] <= 3 and sum(1 for x in gaps if x > 12) <= 8, (sorted(gaps)[-10:], sorted(gaps)[len(gaps) // 2])
 
 
 def test_null_engine_calls_fail_cleanly(mpx_lib):
