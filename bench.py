@@ -172,7 +172,7 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv, stub=False, grace_s=10.0):
+def launch_ranks(n, argv, stub=False, grace_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), wait for them, and
     return a non-zero code if any failed.  The others are then sent SIGTERM and, if they have not exited `grace_s` seconds later (a rank
@@ -181,6 +181,8 @@ def launch_ranks(n, argv, stub=False, grace_s=10.0):
     a GPU: it only COMPILES the library when its stamp is stale (hipcc; the ranks then find a fresh stamp and load it themselves) --
     it does not dlopen it, so no HIP runtime is initialised here and nothing is exec'ed from a process that has one.  With the stub step
     (`--stub-step`, the CPU test hook) nothing is compiled at all."""
+    if grace_s is None:
+        grace_s = float(os.environ.get("MPX_BENCH_KILL_GRACE_S", "10"))
     if not stub:
         import __graft_entry__ as g
         g.compile_only()
@@ -261,6 +263,10 @@ def stub_main(args, rank, world):
     from network_interpretation_imagenet_amd import shard
     if os.environ.get("MPX_BENCH_STUB_FAIL_RANK") == str(rank):      # the launcher test's failing rank: the others must not outlive it
         raise SystemExit(3)
+    if os.environ.get("MPX_BENCH_STUB_DEAF_RANK") == str(rank):      # ... and a rank that ignores SIGTERM (as one blocked in a collective does)
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(600)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -58,6 +58,22 @@ def test_a_failing_rank_fails_the_launcher_and_stops_the_others():
     assert time.time() - t0 < 120          # rank 0 was terminated instead of waiting out the rendezvous timeout
 
 
+def test_a_rank_that_ignores_sigterm_is_killed():
+    """A rank blocked in a collective or a kernel does not act on SIGTERM: the launcher escalates to SIGKILL after its grace period, returns the
+    failing rank's code and leaves no child behind (it used to poll forever)."""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-step", "--images", "2", "--masks", "5"],
+                       env=_env(MPX_BENCH_STUB_FAIL_RANK="1", MPX_BENCH_STUB_DEAF_RANK="0", MPX_BENCH_KILL_GRACE_S="2"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and _json_lines(r.stdout) == []
+    assert "rank 1 exited with 3" in r.stderr and "rank 0 ignored SIGTERM" in r.stderr
+    assert time.time() - t0 < 60
+    import psutil
+    alive = [c for c in psutil.Process().children(recursive=True)
+             if c.is_running() and c.status() != psutil.STATUS_ZOMBIE and "bench.py" in " ".join(c.cmdline())]
+    assert not alive, alive
+
+
 def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-step"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
