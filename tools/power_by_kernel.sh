@@ -28,6 +28,7 @@ one() {   # name layer tile ms-per-launch-estimate
 }
 echo "# tools/power_by_kernel.sh $B $SECS   (idle package power ~260 W, limit 1400 W)"
 one convx_256_1024     layer3.5.conv3  10 1.05
+one convw_256_1024     layer3.5.conv3  14 0.80
 one patch_3x3_256_256  layer3.5.conv2  12 1.06
 one tile256_1024_256   layer3.5.conv1  13 0.60
 one convx_128_512      layer2.1.conv3  10 1.80
