@@ -492,6 +492,8 @@ def prepare_training_data(folder='./masks/', n=IMG):
     return train_x, train_y
 
 
-def score_masks(model, image, segments, onoff, label):
-    """The batched surface: -> (onoff u8[M,S], score f32[M], pred i32[M])."""
-    return model.score_masks(image, segments, onoff, label)
+def score_masks(model, image, segments, onoff, label, stem=None):
+    """The batched surface: -> (onoff u8[M,S], score f32[M], pred i32[M]).  `stem`: None = the engine stages by this call's row
+    count; a caller that scores PART of an image's rows (several calls, several ranks) passes model.stem_for_rows(all of them) so that every
+    part carries the bits of the unsplit call (engine.MaskedForwardEngine.stem_for_rows, shard.job_stem)."""
+    return model.score_masks(image, segments, onoff, label) if stem is None else model.score_masks(image, segments, onoff, label, stem=stem)
