@@ -14,6 +14,11 @@ product on the fp16 MFMA:
     trunk_i8      (iv)  the trunk tensors store lo as a SIGNED BYTE in units of ulp(hi) / 256 (the exponent comes from hi: no scale is
                         stored; 19 significant bits, 3 bytes per element); inner tensors full
     all_i8        (v)   every activation stored that way
+    all_pi8c      (vi)  the one arithmetic family not priced before: corrections as INTEGER slices.  Every activation stores lo as a signed byte with ONE
+                        power-of-two scale per pixel (over all its channels), and both correction products run on the int8 MFMA (twice the fp16 rate, exact
+                        int32 accumulation over the whole K): q8(W_hi).X_lo8 + W_lo8.q8(X_hi) with 8-bit fixed point per pixel / per output channel
+                        -- two units of matrix work instead of three.  Scales chosen independently per term (the optimistic form: sharing one int32
+                        accumulator would tie lo's scale to hi's and cost two more bits)
     act_hi / alt_hi     two-product forms for the MNIST chain, VERDICT r4 item 7 (every / every second conv input as ONE fp16 plane); on the
                         ResNets act_hi is "t1 AND t2 as one plane", the harshest two-product form, for scale
 
@@ -95,6 +100,13 @@ def lo_i8(x, hi):
     return f16(q * unit)
 
 
+def q8_fixed(t, dims):
+    """Symmetric 8-bit fixed point with one power-of-two scale per slice: the largest magnitude over `dims` maps into [64, 127]."""
+    amax = t.abs().amax(dims, keepdim=True)
+    scale = torch.pow(2.0, torch.ceil(torch.log2(torch.clamp(amax, min=2.0 ** -60) / 127.0)))
+    return torch.clamp(torch.round(t / scale), -127.0, 127.0) * scale
+
+
 class Stored:
     """An activation as it sits in memory: hi (fp16 values) + lo (whatever the format keeps of x - hi), both held as fp64."""
     __slots__ = ("hi", "lo")
@@ -115,6 +127,7 @@ POLICIES = {
     "all_e4m3_w8": ("e4m3", "e4m3", True),
     "trunk_i8": ("i8", "x2", False),
     "all_i8": ("i8", "i8", False),
+    "all_pi8c": ("pi8", "pi8", "int8"),
     "act_hi": ("x2", "hi", False),
     "alt_hi": ("x2", "alt", False),          # inner tensors alternate one plane / two planes (the MNIST chain: conv2, conv4, conv6 inputs)
 }
@@ -145,6 +158,8 @@ class Policy:
             return Stored(hi, e4m3_block(x - hi, 1))
         if fmt == "i8":
             return Stored(hi, lo_i8(x, hi))
+        if fmt == "pi8":
+            return Stored(hi, q8_fixed(x - hi, (1,)) if x.dim() == 4 else f16(x - hi))
         raise ValueError(fmt)
 
     def weights(self, key):
@@ -155,7 +170,10 @@ class Policy:
             else:
                 hi = f16(w)
                 lo = f16(w - hi)
-                if self.w8:
+                if self.w8 == "int8":
+                    dims = tuple(range(1, w.dim()))
+                    self.wc[key] = (hi, lo, q8_fixed(hi, dims), q8_fixed(lo, dims))
+                elif self.w8:
                     self.wc[key] = (hi, lo, e4m3_block(hi, 1), e4m3_block(lo, 1))
                 else:
                     self.wc[key] = (hi, lo, None, None)
@@ -172,7 +190,7 @@ class Policy:
             y = F.conv2d(st.hi, w_hi, bias, stride, pad)
             if st.lo is not None:
                 y = y + F.conv2d(st.lo, w_hi8, None, stride, pad)       # st.lo is already on its e4m3 grid (format 'e4m3')
-            return y + F.conv2d(e4m3_block(st.hi, 1), w_lo8, None, stride, pad)
+            return y + F.conv2d(q8_fixed(st.hi, (1,)) if self.w8 == "int8" else e4m3_block(st.hi, 1), w_lo8, None, stride, pad)
         return F.conv2d(st.value(), w_hi + w_lo, bias, stride, pad)
 
     def linear(self, st, wkey, bkey):
