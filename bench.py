@@ -136,7 +136,14 @@ def cpu_baseline(arch, n_masks, eng=None):
         other = "conv" if eng.stem == "table" else None
         if other:
             _o, o_score, o_pred = eng.score_masks(img, seg, onoff, label, stem=other)
-    v, dt, c_score, c_pred = _cpu_loop(arch, n_masks, all_threads, label)
+    # the host's honest best for this loop (SURVEY 8d "all cores and also = 1"): a batch-1 conv does not scale to a
+    # hundred threads, so the same sample (same masks, same batch-1 fp32 loop) runs at 1, 8, 32 and all threads and the BEST is `value`
+    by_threads = {}
+    for th in sorted({1, min(8, all_threads), min(32, all_threads), all_threads}):
+        r = _cpu_loop(arch, n_masks, th, label)
+        by_threads[th] = r
+    best_th = max(by_threads, key=lambda th: by_threads[th][0])
+    v, dt, c_score, c_pred = by_threads[best_th]
     if eng is not None:
         delta = lambda s: float(np.abs(s.astype(np.float64) - c_score.astype(np.float64)).max())
         parity = {"score_max_abs_delta": delta(g_score),
@@ -152,15 +159,20 @@ def cpu_baseline(arch, n_masks, eng=None):
                                        "max_abs_delta_between_stagings": float(np.abs(o_score.astype(np.float64) - g_score.astype(np.float64)).max())}
     c1_all, dt_all, _s, _p = _cpu_loop("resnet18", 64, all_threads)
     c1_one, dt_one, _s, _p = _cpu_loop("resnet18", 16, 1)
+    c1_8, dt_8, _s, _p = _cpu_loop("resnet18", 64, min(8, all_threads))
     torch.set_num_threads(all_threads)
     from oracle import resnet_ref
     gf18 = resnet_ref.flops_per_forward("resnet18") / 1e9
-    base = {"value": v, "unit": "masked-forward-passes/s", "cores": all_threads, "kind": "port",
-            "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s)" % (arch, n_masks, dt),
+    base = {"value": v, "unit": "masked-forward-passes/s", "cores": best_th, "kind": "port",
+            "sample": "%s, 1 image x %d masks, batch-1 fp32 torch-CPU loop (%.1f s), best of %s threads" % (arch, n_masks, dt, sorted(by_threads)),
+            "by_threads": {str(th): {"value": r[0], "seconds": r[1],
+                                     "score_max_abs_delta_vs_best": float(np.abs(r[2].astype(np.float64) - c_score.astype(np.float64)).max())}
+                           for th, r in sorted(by_threads.items())},
             "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(),
             "cfg1_resnet18_1x64": {"all_threads": {"value": c1_all, "threads": all_threads, "seconds": dt_all, "gflops": c1_all * gf18},
                                    "one_thread": {"value": c1_one, "threads": 1, "seconds": dt_one, "gflops": c1_one * gf18,
-                                                  "sample": "16 of the 64 masks"}}}
+                                                  "sample": "16 of the 64 masks"},
+                                   "eight_threads": {"value": c1_8, "threads": min(8, all_threads), "seconds": dt_8, "gflops": c1_8 * gf18}}}
     return base, parity
 
 
@@ -399,6 +411,13 @@ def main(argv=None):
         value = total * args.steps / dt
         cfg_name = {("resnet101", 512, 128): "BASELINE configs[2]" if world == 1 else "BASELINE configs[3] at 8 GPUs",
                     ("resnet18", 256, 32): "BASELINE configs[1]"}.get((args.arch, n_mask, n_img), "custom")
+        # which library was timed: path, hash of the file, its build stamp, and whether that stamp is the hash of THIS tree's sources and
+        # flags (__graft_entry__._source_hash).  A probe build (MPX_LIB_PATH / tools/with_lib.py; possibly timing-only) never carries a
+        # BASELINE workload name
+        bound = _lib.bound_library()
+        bound["lib_stamp_matches_tree"] = bound["lib_stamp"] == g._source_hash(g.lib_sources(), g.HIPCC_FLAGS)
+        if not bound["product_library"]:
+            cfg_name = "custom (probe library)"
         conv_ms, conv_n = prof["ms"]["conv"], prof["launches"]["conv"]
         flops_per_batch = eng.flops_per_forward * batch
         roofline = None
@@ -443,6 +462,9 @@ def main(argv=None):
             "config": {"workload": "%s, %d masks/image x %d images per GPU (%s; x%d GPUs)" % (args.arch, n_mask, n_img, cfg_name, world),
                        "images_per_gpu": n_img, "masks_per_image": n_mask, "forward_batch": batch, "num_cus": eng.num_cus,
                        "entry": "MaskedForwardEngine.score_packed", "stem": eng.stem,
+                       "lib_path": os.path.relpath(bound["lib_path"], ROOT) if bound["product_library"] else bound["lib_path"],
+                       "lib_sha256": bound["lib_sha256"], "lib_stamp": bound["lib_stamp"],
+                       "lib_stamp_matches_tree": bound["lib_stamp_matches_tree"], "product_library": bound["product_library"],
                        "parallelism": "mask-batch shard x%d + one all_gather of scores" % world},
             "tflops_algorithmic": value * eng.flops_per_forward / 1e12,
             "roofline": roofline,

@@ -288,10 +288,14 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
                            const int32_t* label, int M, int S, float* heat, void* stream);
 
 /* ---- introspection for tests / benchmarks --------------------------------------------------- */
-/* DEV pointers of the padded NHWC4 input staging planes: fp16 [max_batch][230][230][4].  A caller may write them (tests do): the call marks
- * every slot as staged through these planes, so the next mpx_forward runs the stem conv + max pool on them even if an earlier batch of the
- * same slots came from mpx_stem_table_apply (which marks the slots it writes as its own again). */
-int mpx_input_planes(mpx_engine* h, void** hi, void** lo);
+/* DEV pointers of the input staging planes: fp16 [max_batch][230][230][4] (padded NHWC4) for the ImageNet ResNets, [max_batch][H][W][32] for
+ * the small networks.  A pure getter: the record of how each slot was staged is not touched, so a diagnostic call between
+ * mpx_stem_table_apply and mpx_forward changes nothing. */
+int mpx_input_planes(const mpx_engine* h, void** hi, void** lo);
+/* A caller that has WRITTEN the input planes of slots [slot0, slot0+M) by hand declares them staged, as mpx_mask_apply_normalize does for the
+ * slots it fills: the next mpx_forward runs the stem conv + max pool on them even if an earlier batch of the same slots came from
+ * mpx_stem_table_apply (which marks the slots it writes as its own again).  MPX_E_ARG outside [0, max_batch). */
+int mpx_mark_input_staged(mpx_engine* h, int slot0, int M);
 /* DEV pointers of the pooled stem output planes: fp16 [max_batch][56][56][64], written by the stem + max pool launch of mpx_forward or by
  * mpx_stem_table_apply (NULL for the small networks, which have no such stem). */
 int mpx_stem_planes(const mpx_engine* h, void** hi, void** lo);

@@ -11,7 +11,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPX_LIB_PATH: another build of the library for this process AND the processes it starts (tools/with_lib.py sets it for a probe
 # build, so that `bench.py --gpus N`'s child ranks bind what the parent was told to bind); unset = the product library in the tree
-LIB_PATH = os.environ.get("MPX_LIB_PATH") or os.path.join(_HERE, "libmpx.so")
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libmpx.so")
+LIB_PATH = os.environ.get("MPX_LIB_PATH") or PRODUCT_LIB_PATH
 
 IMG = 224
 IMG_PAD = 230
@@ -68,6 +69,7 @@ SIGNATURES = {
     "mpx_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mpx_heatmap_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mpx_input_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mpx_mark_input_staged": (_i, [_vp, _i, _i]),
     "mpx_stem_planes": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "mpx_profile_enable": (_i, [_vp, _i]),
     "mpx_profile_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
@@ -84,6 +86,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MpxError("HIP extension %s not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        if is_probe_build():
+            import sys
+            sys.stderr.write("mpx: binding %s (MPX_LIB_PATH / with_lib.py) -- NOT the product library %s; probe builds may be timing-only\n"
+                             % (LIB_PATH, PRODUCT_LIB_PATH))
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
@@ -91,6 +97,27 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def is_probe_build():
+    """True when this process binds anything but the in-tree product library (MPX_LIB_PATH, tools/with_lib.py)."""
+    return os.path.realpath(LIB_PATH) != os.path.realpath(PRODUCT_LIB_PATH)
+
+
+def bound_library():
+    """What a record of a run must carry to say WHICH library it ran (bench.py's config): the path this process binds, the
+    sha256 of that file, the build stamp next to it (`<lib>.sha256` = __graft_entry__._source_hash of the sources and flags it was built
+    from; None when there is none) and whether it is the in-tree product library."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    stamp = None
+    if os.path.exists(LIB_PATH + ".sha256"):
+        with open(LIB_PATH + ".sha256") as fh:
+            stamp = fh.read().strip()
+    return {"lib_path": LIB_PATH, "lib_sha256": h.hexdigest(), "lib_stamp": stamp, "product_library": not is_probe_build()}
 
 
 def check(handle, rc, what):

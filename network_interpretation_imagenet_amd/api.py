@@ -93,6 +93,10 @@ class SaliencySession:
         self.upper_bound = masks.bo_upper_bound(self.num_segments)
         self._table = None
         self.base_pred = None
+        # ONE staging for everything this session ever scores (the two stagings round differently, <= 2.5e-6 on a score): the kind an image
+        # with S + 2 rows gets -- the unmasked row + every window start, what fill_tables packs -- whether the table is computed here with or
+        # without the unmasked row, by fill_tables next to other images, or a single window is scored outside the table
+        self.stem = engine.stem_for_rows(self.num_segments + 2) if hasattr(engine, "stem_for_rows") else None
         if check_base:
             # the unmasked row rides in the same forward batch as the S + 1 window starts every caller asks for next (as
             # fill_tables does for several images): one pass instead of a batch-1 forward -- ~4 ms of kernel latencies on
@@ -100,15 +104,20 @@ class SaliencySession:
             # score does not depend on the slot it is computed in.
             onoff = np.concatenate([np.ones((1, self.num_segments), dtype=np.uint8),
                                     masks.windows_onoff(self.num_segments, range(0, self.num_segments + 1))])
-            _o, score, pred = engine.score_masks(self.input, self.seg_rank, onoff, self.label)
+            _o, score, pred = self._score(onoff)
             self.base_pred = int(pred[0])
             if self.base_pred != self.label:
                 raise BasePredictionWrong("unmasked prediction %d != label %d" % (self.base_pred, self.label))
             self._table = (score[1:], pred[1:])
 
+    def _score(self, onoff):
+        if self.stem is None:           # an engine without the two stagings (test doubles)
+            return self.engine.score_masks(self.input, self.seg_rank, onoff, self.label)
+        return self.engine.score_masks(self.input, self.seg_rank, onoff, self.label, stem=self.stem)
+
     def score_windows(self, first_indices):
         onoff = masks.windows_onoff(self.num_segments, first_indices)
-        _o, score, pred = self.engine.score_masks(self.input, self.seg_rank, onoff, self.label)
+        _o, score, pred = self._score(onoff)
         return onoff, score, pred
 
     def table(self):
@@ -293,7 +302,10 @@ def fill_tables(engine, sessions):
     (MaskedForwardEngine.score_images: the rows of consecutive images share batches of up to max_batch slots) -- one image's
     table is only S+2 = 50 .. 350 rows, a fraction of the batch the engine is fast at.  Sets each session's base_pred and
     table; -> [bool]: the unmasked prediction equals the label (the reference's gate, generate_gp_training_data_imagenet.py:215).
-    Scores are bit-identical to SaliencySession.table() one image at a time."""
+    Every image is staged by ITS OWN S + 2 rows (SaliencySession.stem = engine.stem_for_rows(S + 2), the same rule score_images applies per
+    image), so its scores are bit-identical to SaliencySession.table() of that image alone, whatever it is packed with: the binary labels
+    (generate_gp_training_data_imagenet.py:248,257) and the heat-map sum (gp_superpixel_data_imagenet.py:322-323) do not depend on grouping
+    or lookahead."""
     todo = [s for s in sessions if s._table is None or s.base_pred is None]
     if todo:
         rows = []

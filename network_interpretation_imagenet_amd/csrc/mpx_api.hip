@@ -602,6 +602,10 @@ bool convw_eligible(const ConvLayer& L) { return conv256_eligible(L) && L.cin_pa
 
 int launch_convw(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (p.ktot != ConvW::K) return fail(h, MPX_E_INTERNAL, "convw: K = %d (the kernel holds K = %d in registers)", p.ktot, ConvW::K);
+    // The kernel serves what every layer it is the default for asks of it and what the parity tests cover: the residual add + ReLU of a block's
+    // last conv.  A call through mpx_conv_bn_act WITHOUT a residual or (no such layer exists in the networks) without ReLU takes tile 10's
+    // kernel, which sums in the same order: only <K, RELU = true> is instantiated (the <false> and null-residual paths had no test).
+    if (!p.relu || !p.r_hi) return launch_convx(h, p, cout_pad, st);
     p.n_tiles_c = p.cout / ConvW::TC;
     if (p.n_tiles_c * ConvW::TC > cout_pad) return fail(h, MPX_E_ARG, "conv tile exceeds the packed weight rows");
     const long long n_tiles_p = ((long long)p.M + ConvW::TP - 1) / ConvW::TP;
@@ -614,8 +618,7 @@ int launch_convw(mpx_engine* h, ConvParams& p, int cout_pad, hipStream_t st) {
     if (grid <= 0 || total < 2LL * h->num_cus) return launch_conv_tile<ConvTile7>(h, p, cout_pad, st);
     // (the kernel is a template over K; K = 128 -- 128 -> 512 on 28 x 28 maps -- was built and measured in round 5: parity green, bit-equal to tile 10, and a
     // tie with it, 7.26 against 7.19 ms for the four layers: two stages of the epilogue slice per MFMA gap do not hide any more.  Only K = 256 is instantiated.)
-    if (p.relu) hipLaunchKernelGGL((convw_f16x3_kernel<ConvW::K, true>), dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
-    else hipLaunchKernelGGL((convw_f16x3_kernel<ConvW::K, false>), dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
+    hipLaunchKernelGGL((convw_f16x3_kernel<ConvW::K, true>), dim3((unsigned)grid), dim3(ConvW::NT), ConvW::LDS, st, p);
     MPX_HIP(h, hipGetLastError());
     h->last_kernels |= 1u << 14;
     return 0;
@@ -1266,8 +1269,6 @@ int mpx_create(int arch_id, int max_batch, int device, mpx_engine** out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<ConvW::K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)convw_f16x3_kernel<ConvW::K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvW::LDS);
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv256p_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Conv256P::LDS);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_f16x3_kernel<ConvTile4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvTile4::LDS);
@@ -1825,14 +1826,21 @@ int mpx_heatmap_accumulate(mpx_engine* h, const int32_t* seg, const uint8_t* ono
     return 0;
 }
 
-int mpx_input_planes(mpx_engine* h, void** hi, void** lo) {
+int mpx_input_planes(const mpx_engine* h, void** hi, void** lo) {
     if (!h || !hi || !lo) return MPX_E_ARG;
-    *hi = h->in_hi;
-    *lo = h->in_lo;
-    // whoever asks for these pointers may write the staging by hand: from here on every slot counts as staged THROUGH the input planes
-    // (the next forward runs the stem conv on them) until mpx_stem_table_apply marks slots as its own again -- a forward must never skip
-    // the stem over planes a caller has just written because an earlier batch of those slots came from the table
-    std::fill(h->slot_src.begin(), h->slot_src.end(), (uint8_t)1);
+    *hi = h->in_hi;             // a pure getter: how the slots were staged (slot_src) is not touched -- a diagnostic call between
+    *lo = h->in_lo;             // mpx_stem_table_apply and mpx_forward must not turn the forward onto stale input planes
+    return 0;
+}
+
+int mpx_mark_input_staged(mpx_engine* h, int slot0, int M) {
+    if (!h) return MPX_E_ARG;
+    if (slot0 < 0 || M <= 0 || (long long)slot0 + M > h->max_batch)
+        return fail(h, MPX_E_ARG, "mark_input_staged: slots [%d, %d) outside [0, max_batch=%d)", slot0, slot0 + M, h->max_batch);
+    if (h->in_forward) return fail(h, MPX_E_STATE, "mark_input_staged: called during mpx_forward");
+    // a caller that has WRITTEN the input planes of these slots by hand (mpx_input_planes) says so: the next mpx_forward runs the stem
+    // conv + max pool on them, as after mpx_mask_apply_normalize, even if an earlier batch of the same slots came from mpx_stem_table_apply
+    std::fill(h->slot_src.begin() + slot0, h->slot_src.begin() + slot0 + M, (uint8_t)1);
     return 0;
 }
 

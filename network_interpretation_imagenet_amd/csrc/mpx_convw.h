@@ -108,7 +108,8 @@ __device__ __forceinline__ unsigned cw_pack_lo(unsigned hi, float one, float a, 
 
 template <int KK>
 struct ConvWK {
-    static_assert(KK == 128 || KK == 256, "64 output channels x K x (hi + lo) must fit a wave's 256 AGPRs, and a column's MFMAs must cover an epilogue slice");
+    static_assert(KK == 256, "64 output channels x K x (hi + lo) fill a wave's 256 AGPRs.  K = 128 was built and measured in round 5 (a tie with convx, DESIGN 5e) and is NOT "
+                             "shipped: with NK = 4 an epilogue stage starts 3 MFMAs behind the column's last accumulator write, not the 5 the hazard comment in the kernel relies on");
     static constexpr int TC = 256, TP = 64, NW = 4, NT = 256;
     static constexpr int K = KK, NK = K / 32;
     static constexpr int STAGE = 8192;                  // one K step of the pixel tile: [X_hi 64 rows x 64 B | X_lo 64 rows x 64 B]
@@ -400,8 +401,10 @@ __global__ __launch_bounds__(256, 1) void convw_f16x3_kernel(const ConvParams p)
         column(std::integral_constant<int, 1>{}, ti, buf);
         column(std::integral_constant<int, 2>{}, ti, buf);
         column(std::integral_constant<int, 3>{}, ti, buf);
-        // The next tile's 16 pieces were issued in columns 0 and 1; behind them: column 1's stores (4), columns 2 and 3 (4 loads + 4 stores
-        // each).  Behind the barrier all four waves' pieces have landed and nobody reads this tile's buffer again.
+        // The next tile's 16 pieces were issued in columns 0 and 1; behind the last of them: column 1's residual loads (4) and stores (4),
+        // then columns 2 and 3 (4 loads + 4 stores each) = 24 = TILE_END_WAIT with the default placements (the ISA test counts them:
+        // tests/test_host_logic.py test_convw_k_loop_is_what_the_source_says).  Behind the barrier all four waves' pieces have landed and
+        // nobody reads this tile's buffer again.
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::TILE_END_WAIT) : "memory");
         __builtin_amdgcn_s_barrier();

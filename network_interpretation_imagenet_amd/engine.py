@@ -98,8 +98,9 @@ class MaskedForwardEngine:
     def __init__(self, arch="resnet101", max_batch=512, device=None, stem=None):
         """stem: how score_packed / score_masks / score_images stage the masks of an image on the ImageNet ResNets --
         "table" (default): the stem by superposition (mpx_stem_table_build once per image, mpx_stem_table_apply per block of mask rows:
-        K0, the stem conv and its max pool for all masks of an image without materialising a masked image) whenever a call brings at
-        least `stem_table_min_rows` (256) rows per image, K0 + the MFMA stem otherwise (a BO round's 28 .. 118 windows); "conv": always
+        K0, the stem conv and its max pool for all masks of an image without materialising a masked image) for every IMAGE that brings at
+        least `stem_table_min_rows` (256) rows -- decided per image, however the rows are packed into calls and batches --, K0 + the MFMA
+        stem otherwise (a BO round's 28 .. 118 windows); "conv": always
         K0 into the input staging, then the MFMA stem + max pool inside the forward (rounds 1-3).  stage_masks() is always K0."""
         if arch not in ARCH_IDS:
             raise ValueError("unsupported arch %r (torchvision ResNets and the reference's small networks: %s)" % (arch, sorted(ARCH_IDS)))
@@ -138,17 +139,17 @@ class MaskedForwardEngine:
         self.stem = "conv" if self.small else (stem or "table")
 
     def stem_for_rows(self, rows_per_image):
-        """The staging a JOB of `rows_per_image` mask rows per image gets on this engine: "table" (the stem by superposition) from
+        """The staging an IMAGE that brings `rows_per_image` mask rows to a job gets on this engine: "table" (the stem by superposition) from
         `stem_table_min_rows` rows on, "conv" (K0 + the MFMA stem) below or when the engine was created with stem="conv".  The two stagings
         round differently (<= 2.5e-6 on a score), so whoever SPLITS a job -- shard.score_masks_sharded / heatmap_sharded over ranks, a caller
         cutting an image's rows into several calls -- decides ONCE from the job's row count with this function and hands the answer to
         every call as `stem=`: the shards then carry the bits of the unsplit call."""
         return "table" if (self.stem == "table" and int(rows_per_image) >= self.stem_table_min_rows) else "conv"
 
-    def _staging(self, stem, rows, images=1):
-        """Resolve a call's `stem=` argument: None = decide from the call's own rows per image (stem_for_rows), else the caller's choice."""
+    def _staging(self, stem, rows):
+        """Resolve the `stem=` argument for ONE image that brings `rows` mask rows: None = stem_for_rows(rows), else the caller's choice."""
         if stem is None:
-            return self.stem_for_rows(rows // max(1, images))
+            return self.stem_for_rows(rows)
         if stem not in ("table", "conv"):
             raise ValueError("stem must be None, 'table' or 'conv', got %r" % (stem,))
         if stem == "table" and self.small:
@@ -300,7 +301,7 @@ class MaskedForwardEngine:
 
     def input_planes(self, n=None):
         """Zero-copy fp16 views of the engine-owned input staging planes (hi, lo), shaped input_plane_shape(n).
-        For tests and diagnostics."""
+        For tests and diagnostics; reading them changes nothing.  Whoever WRITES slots by hand calls mark_input_staged() before forward()."""
         n = self.max_batch if n is None else int(n)
         if not 0 < n <= self.max_batch:
             raise ValueError("input_planes: n must be in [1, max_batch=%d]" % self.max_batch)
@@ -314,6 +315,10 @@ class MaskedForwardEngine:
 
         return (torch.as_tensor(_View(hi.value), device=self.device),
                 torch.as_tensor(_View(lo.value), device=self.device))
+
+    def mark_input_staged(self, slot0, m):
+        """mpx_mark_input_staged: slots [slot0, slot0+m) of the input planes were written by hand -- the next forward runs the stem on them."""
+        _lib.check(self._h, self._lib.mpx_mark_input_staged(self._h, int(slot0), int(m)), "mpx_mark_input_staged")
 
     def stem_planes(self, n=None):
         """Zero-copy fp16 views (hi, lo) [n,56,56,64] of the engine-owned pooled stem output planes (ImageNet ResNets).  For tests."""
@@ -450,11 +455,13 @@ class MaskedForwardEngine:
         gp_superpixel_data_imagenet.py:299-307).  images: sequence of device tensors (u8[224,224,3] or f32[3,224,224]);
         segs: ONE device i32[224,224] rank map shared by all images, or a sequence with one per image; onoffs: sequence of
         device u8[M_i, S_i]; label_rows: device i32[sum M_i] (image i's label repeated M_i times); score_out f32 / pred_out
-        i32 [sum M_i] receive the results.  Allocates nothing, synchronises nothing.  ONE kind of staging per call (a forward takes its slots
-        from one of the two): `stem` = "table" / "conv", or None = the table when the call brings at least stem_table_min_rows rows per image
-        with rows ON AVERAGE (stem_for_rows).  Within one staging a row's bits depend neither on where it sits in a batch nor on what else the
-        call scores (kernel choice does not depend on the position of a mask): results are bit-identical to scoring every image on its own
-        with the same `stem`."""
+        i32 [sum M_i] receive the results.  Allocates nothing, synchronises nothing.  Staging is decided PER IMAGE, from that image's own
+        row count: `stem` = None stages image i by stem_for_rows(M_i) (the table from stem_table_min_rows rows on, K0 + the MFMA stem below),
+        "table" / "conv" force one kind for every image of the call (a caller that hands over PART of an image's rows passes
+        stem_for_rows(all of them)).  A forward takes its slots from one kind of staging (mpx_forward refuses a mixed batch), so the pending
+        forward is flushed where the kind changes between consecutive images -- callers that can reorder (score_images) group the images by
+        kind first.  A row's bits depend neither on where it sits in a batch nor on what else the call scores (kernel choice does not depend
+        on the position of a mask, staging only on the row's own image): results are bit-identical to scoring every image on its own."""
         n = len(images)
         shared = isinstance(segs, torch.Tensor)
         if len(onoffs) != n or (not shared and len(segs) != n):
@@ -466,31 +473,45 @@ class MaskedForwardEngine:
         label_rows, score_out, pred_out = label_rows.view(-1), score_out.view(-1), pred_out.view(-1)
         done = 0            # rows already handed to a forward
         used = 0            # slots staged for the next forward
-        table = self._staging(stem, total, sum(1 for o in onoffs if int(o.shape[0]))) == "table"
+        used_kind = None    # how those slots were staged
+        if stem is not None:
+            self._staging(stem, 0)
+
+        def flush():
+            nonlocal done, used
+            self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
+            done += used
+            used = 0
+
         for i in range(n):
             m, r = int(onoffs[i].shape[0]), 0
+            if not m:
+                continue
             seg = segs if shared else segs[i]
-            if table and m:
+            kind = self.stem_for_rows(m) if stem is None else stem
+            if used and kind != used_kind:
+                flush()                 # one forward, one kind of staging
+            used_kind = kind
+            if kind == "table":
                 self.build_stem_table(images[i], seg, int(onoffs[i].shape[1]))      # once per image; its rows follow in one or two forwards
             while r < m:
                 take = min(m - r, self.max_batch - used)
-                if table:
+                if kind == "table":
                     self.apply_stem_table(onoffs[i][r:r + take], used)
                 else:
                     self.stage_masks(images[i], seg, onoffs[i][r:r + take], used)
                 used += take
                 r += take
                 if used == self.max_batch:
-                    self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
-                    done += used
-                    used = 0
+                    flush()
         if used:
-            self.forward(used, label_rows[done:done + used], score_out=score_out[done:done + used], pred_out=pred_out[done:done + used])
+            flush()
 
     def score_images(self, images, segments, onoffs, labels, stem=None):
         """Host convenience over score_packed: [(image, segments, onoff u8[M_i,S_i], label)] for several images ->
         [(score f32[M_i], pred i32[M_i])], with ONE upload of the inputs and ONE download of all scores.  `segments` are
-        arbitrary integer label maps (ranked here as score_masks does); `stem` as in score_packed."""
+        arbitrary integer label maps (ranked here as score_masks does); `stem` as in score_packed: None stages every image by its own row
+        count, so an image gets the same bits here as when it is scored alone, whatever it is packed with."""
         if self.small:
             raise ValueError("%s scores with score_masks_removed (the small networks' mask convention)" % self.arch)
         n = len(images)
@@ -515,15 +536,28 @@ class MaskedForwardEngine:
         total = int(sum(sizes))
         if total == 0:
             return [(np.empty(0, np.float32), np.empty(0, np.int32)) for _ in range(n)]
-        label_rows = torch.from_numpy(np.concatenate(lab)).to(self.device)
+        # every image is staged by ITS OWN row count (score_packed); the images of one kind go first so that the forward is flushed at most
+        # once for the change of kind (stable: the order within a kind is the caller's)
+        order = list(range(len(img_d)))
+        if stem is None:
+            order.sort(key=lambda k: self.stem_for_rows(int(onoff_d[k].shape[0])) != "table")
+        label_rows = torch.from_numpy(np.concatenate([lab[k] for k in order])).to(self.device)
         score = torch.empty(total, dtype=torch.float32, device=self.device)
         pred = torch.empty(total, dtype=torch.int32, device=self.device)
-        self.score_packed(img_d, seg_d, onoff_d, label_rows, score, pred, stem=stem)
+        self.score_packed([img_d[k] for k in order], [seg_d[k] for k in order], [onoff_d[k] for k in order], label_rows, score, pred, stem=stem)
         score, pred = score.cpu().numpy(), pred.cpu().numpy()
-        out, at = [], 0
-        for m in sizes:
-            out.append((score[at:at + m].copy(), pred[at:at + m].copy()))
+        packed, at = {}, 0
+        for k in order:
+            m = int(onoff_d[k].shape[0])
+            packed[k] = (score[at:at + m].copy(), pred[at:at + m].copy())
             at += m
+        out, k = [], 0
+        for m in sizes:
+            if m == 0:
+                out.append((np.empty(0, np.float32), np.empty(0, np.int32)))
+            else:
+                out.append(packed[k])
+                k += 1
         return out
 
     def predict(self, image):

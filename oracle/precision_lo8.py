@@ -34,6 +34,12 @@ generate_gp_training_data_cifar.py:271-321 / ..._mnist.py:163-243 do (oracle/sma
 
     python oracle/precision_lo8.py [resnet18,resnet101,cifar_resnet56,mnist_net] [pictures=5] [masks=64] [policies=...]
 
+Round 6 (the hardened gate of the integer-slice family): `resnet18_tl` / `resnet101_tl` are the same topologies with
+TRAINED-LIKE BatchNorm statistics on every layer (oracle/trained_like.py: per-channel tuples resampled from the CIFAR checkpoint, conv weights
+calibrated so that the statistics hold), and LO8_SMALL_EXTRA=10 puts both shipped checkpoints on 12 pictures x 24 masks:
+
+    LO8_SMALL_EXTRA=10 python oracle/precision_lo8.py resnet18_tl,resnet101_tl,cifar_resnet56,mnist_net 8 64 full,all_pi8c
+
 Gate: a format may become a kernel only if its worst score error over everything is <= 5e-5 (the north-star's tolerance is 1e-4; the
 same gate the two-product form failed in round 4).  Result of this script in the build container: profiles/r05_precision_lo8.txt.
 """
@@ -168,8 +174,16 @@ class Policy:
             if self.name == "f64":
                 self.wc[key] = (w, None, None, None)
             else:
-                hi = f16(w)
-                lo = f16(w - hi)
+                # as the engine packs them (mpx_pack_conv_weights): every output channel is multiplied by the power of two that puts its largest
+                # magnitude into [512, 1024) before the split, so that `lo` stays out of fp16's subnormal range; the epilogue's scale takes the
+                # 2^-e back.  (Up to round 5 this script split the raw weights: on calibrated / trained-like networks whose channels carry
+                # weights of 1e-3 the `lo` plane fell under 2^-24 and the "full" format looked like 13 bits -- 1.0e-3 on resnet101_tl.)
+                amax = w.abs().flatten(1).amax(1).clamp(min=2.0 ** -60)
+                e = (9.0 - torch.floor(torch.log2(amax))).reshape((-1,) + (1,) * (w.dim() - 1))
+                ws = w * torch.pow(2.0, e)
+                hi = f16(ws)
+                lo = f16(ws - hi) * torch.pow(2.0, -e)
+                hi = hi * torch.pow(2.0, -e)
                 if self.w8 == "int8":
                     dims = tuple(range(1, w.dim()))
                     self.wc[key] = (hi, lo, q8_fixed(hi, dims), q8_fixed(lo, dims))
@@ -299,7 +313,13 @@ def score_err(lg, ref, label):
 
 
 def sweep_imagenet(arch, n_pic, n_mask, policies):
-    sd64 = R.cast_state_dict(synth.make_state_dict(arch), torch.float64)
+    if arch.endswith("_tl"):        # trained-like BatchNorm statistics on every layer (oracle/trained_like.py)
+        from oracle import trained_like
+        arch_name, arch = arch, arch[:-3]
+        sd64 = R.cast_state_dict(trained_like.make_trained_like_state_dict(arch), torch.float64)
+    else:
+        arch_name = arch
+        sd64 = R.cast_state_dict(synth.make_state_dict(arch), torch.float64)
     worst = {}
     for kind, i, img, seg, onoff in imagenet_cases(n_pic, n_mask):
         t0 = time.time()
@@ -310,7 +330,7 @@ def sweep_imagenet(arch, n_pic, n_mask, policies):
         e = {p: score_err(forward(arch, sd64, xb, p)[1:], ref[1:], label) for p in policies}
         pr = torch.softmax(ref[1:], 1)[:, label]
         print("%-14s %-7s pic %d  S=%-4d label %-4d scores %.3f..%.3f   %s   (%.0f s)" % (
-            arch, kind, i, onoff.shape[1], label, float(pr.min()), float(pr.max()), "   ".join("%s %.2e" % (p, e[p]) for p in policies),
+            arch_name, kind, i, onoff.shape[1], label, float(pr.min()), float(pr.max()), "   ".join("%s %.2e" % (p, e[p]) for p in policies),
             time.time() - t0), flush=True)
         for p, v in e.items():
             worst[(kind, p)] = max(worst.get((kind, p), 0.0), v)
@@ -402,7 +422,8 @@ if __name__ == "__main__":
         pol = list(policies)
         if arch == "mnist_net" and "alt_hi" not in pol:
             pol.append("alt_hi")
-        worst = sweep_small(arch, pol) if (arch == "mnist_net" or arch.startswith("cifar")) else sweep_imagenet(arch, n_pic, n_mask, pol)
+        worst = (sweep_small(arch, pol, extra=int(os.environ.get("LO8_SMALL_EXTRA", "4"))) if (arch == "mnist_net" or arch.startswith("cifar"))
+                 else sweep_imagenet(arch, n_pic, n_mask, pol))
         for (kind, p), v in sorted(worst.items()):
             print("== %-14s %-8s %-12s worst score error %.2e" % (arch, kind, p, v), flush=True)
             overall[p] = max(overall.get(p, 0.0), v)

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suite vouches for the PRODUCT library: a leaked MPX_LIB_PATH (tools/with_lib.py's probe builds, possibly timing-only) would make
+    # every parity test speak for another binary
+    if os.environ.get("MPX_LIB_PATH"):
+        raise pytest.UsageError("MPX_LIB_PATH=%s is set: the tests run against the in-tree libmpx.so only; unset it" % os.environ["MPX_LIB_PATH"])
 
 
 @pytest.fixture(scope="session")
