@@ -350,6 +350,26 @@ def test_stress_sweep_distinct_shapes(eng101):
     assert n >= 3 * 60 and worst <= 4e-6
 
 
+def test_stress_sweep_trained_like_weights(mpx_lib, dev):
+    """The same sweep with the conv + BatchNorm pairs of the trained-like ResNet-101 (oracle/trained_like.py: running variances 4e-6 .. 100,
+    means up to 4 sigma, gammas -0.2 .. 1.6, calibrated weights with a common-mode component): every distinct shape x every eligible kernel
+    tile against the fp64 conv + BN, the same 4e-6 relative bound as on the synthetic initialisation."""
+    import importlib.util
+    from oracle import trained_like
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    sd = trained_like.make_trained_like_state_dict("resnet101")
+    eng = MaskedForwardEngine("resnet101", max_batch=8, device=0).load_state_dict(sd)
+    try:
+        layers = sp.distinct_shape_layers(eng)
+        n, worst = sp.sweep(eng, sd, layers, [3, 7], seed=5)
+        print("stress sweep, trained-like weights: %d (layer, batch, tile) cases, worst relative error %.2e" % (n, worst))
+        assert n >= 2 * 60 and worst <= 4e-6
+    finally:
+        eng.close()
+
+
 def test_heatmap_device_and_one_buffer_layout(eng18):
     """engine.heatmap_device (what shard.heatmap_sharded runs per rank): scores + K5 into a device buffer f32[224*224 + 1] whose last
     element counts the correct masks -- equal to the host-array path exactly; a second image accumulates on top."""
