@@ -20,6 +20,13 @@
 #pragma once
 #include "mpx_conv3p.h"
 
+// timing-only ablations (probe builds, wrong results): bit 0 = no fragment reads from LDS, 1 = weight DMAs carry an out-of-range offset
+// (issued and counted, no access), 2 = patch DMAs likewise, 3 = stores likewise, 4 = no step barrier, 5 = no MFMAs,
+// 6 = the fragments ARE read from LDS (fresh data, into the set `fb`) but every MFMA takes the set `fa` of the prologue (constant operands)
+#ifndef P3_ABL
+#define P3_ABL 0
+#endif
+
 namespace mpx {
 
 template <class C>
@@ -151,8 +158,8 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         for (int j = 0; j < WJ; ++j) {
             const int d = (j * NW + wave) * 1024;
             const int ps = soff + (j * NW + wave) * 16 * p.ktot * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_lane | dead, ps, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_lane | dead, ps, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_hi, MPX_LDS_PTR(sb + OFF_WHI + d), 16, w_lane | dead | ((P3_ABL & 2) ? (int)OOB : 0), ps, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs_lo, MPX_LDS_PTR(sb + OFF_WLO + d), 16, w_lane | dead | ((P3_ABL & 2) ? (int)OOB : 0), ps, 0, 0);
         }
     };
     // piece i of this wave for `chunk` (nchunks = chunk 0 of the next tile, whose offsets xo already holds) into patch buffer chunk & 1
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         char* sl = inside ? sb + R * 64 : sb;
         const int dead = inside ? 0 : (int)OOB;
         const int soff = (chunk >= nchunks ? chunk - nchunks : chunk) * 64;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb), 16, xo[i] | dead, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sl), 16, xo[i] | dead, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_hi, MPX_LDS_PTR(sb), 16, xo[i] | dead | ((P3_ABL & 4) ? (int)OOB : 0), soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs_lo, MPX_LDS_PTR(sl), 16, xo[i] | dead | ((P3_ABL & 4) ? (int)OOB : 0), soff, 0, 0);
     };
 
     f4 acc[CF][PF];
@@ -185,6 +192,10 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         }
     };
     auto load_frag = [&](int wslot, int pbuf, Frags& f, int j) {
+        if (P3_ABL & 1) {
+            asm volatile("" : "+v"(f.a_hi[0]), "+v"(f.b_hi[0]));
+            return;
+        }
         const char* sw = smem + wslot * WSTAGE;
         const char* sx = smem + XBASE + pbuf * PSTG;
         if (j < CF) f.a_hi[j] = *(const h8*)(sw + OFF_WHI + a_off + j * 1024);
@@ -193,6 +204,10 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         else f.b_lo[j - 2 * CF - PF] = *(const h8*)(sx + R * 64 + baddr[j - 2 * CF - PF]);
     };
     auto mfma_one = [&](const Frags& f, int i) {
+        if (P3_ABL & 32) {
+            asm volatile("" : "+v"(acc[0][0]));
+            return;
+        }
         const int a = i / (3 * PF), r = i % (3 * PF), term = r / PF, b = r % PF;
         if (term == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a_hi[a], f.b_lo[b], acc[a][b], 0, 0, 0);
         else if (term == 1) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a_lo[a], f.b_hi[b], acc[a][b], 0, 0, 0);
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         int offA[PF];
         {
             const int co = n0 + wr * 64 + (2 * ((l_ & 8) ? 1 : 0) + (erow & 1)) * 16 + (erow >> 1) * 8;
-            const int dead = (p.cout - 1 - co) & (int)OOB;
+            const int dead = ((p.cout - 1 - co) & (int)OOB) | ((P3_ABL & 8) ? (int)OOB : 0);
 #pragma unroll
             for (int b = 0; b < PF; ++b) offA[b] = ((wc * (TP / C::NWC) + b * 16 + (l_ & 7)) * p.cout + co) * 2 | dead;
         }
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         __builtin_amdgcn_sched_barrier(0);
         if (T < 2 && after_epi) wait_vmcnt<C::wait_at(T) + EPI_STORES>();
         else wait_vmcnt<C::wait_at(T)>();
-        __builtin_amdgcn_s_barrier();
+        if (!(P3_ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int nw = (wslot + 1 == 3) ? 0 : wslot + 1;
         constexpr int TN = (T + 1) % 9;
@@ -302,12 +317,15 @@ __global__ __launch_bounds__(C::NT, 1) void conv3x3pp_f16x3_kernel(const ConvPar
         if (T == 8 && next_ti >= 0) set_rows(next_ti);
         set_baddr(TN);
         __builtin_amdgcn_sched_barrier(0);
+        const Frags& use = (P3_ABL & 64) ? fa : cur;
+        Frags& fill = (P3_ABL & 64) ? fb : nxt;
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            mfma_one(cur, i);
+            mfma_one(use, i);
             __builtin_amdgcn_sched_barrier(0);
             if ((i & 1) == 0 && i / 2 < NF) {
-                load_frag(nw, cn & 1, nxt, i / 2);
+                load_frag(nw, cn & 1, fill, i / 2);
+                if (P3_ABL & 64) asm volatile("" ::"v"(fill.a_hi[0]), "v"(fill.a_lo[0]), "v"(fill.b_hi[0]), "v"(fill.b_lo[0]));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i == 1) {
