@@ -324,7 +324,8 @@ def fill_tables(engine, sessions):
 def _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, lookahead, emit):
     """Common driver of validate_many / validate_summed_many: one pass over the loader; the CPU segmentation of the next
     images (segment.SegmenterPool) runs while the GPU scores the current group; the tables of consecutive images are packed
-    into full forward batches (fill_tables).  emit(index, session, firsts, correct) -> the per-image result."""
+    into full forward batches (fill_tables), one group per kind of staging.  emit(index, session, firsts, correct) -> the per-image
+    result, called in loader order."""
     from collections import deque
     from . import segment
     n = _CONFIG["num_mask_samples"] if num_mask_samples is None else num_mask_samples
@@ -336,27 +337,42 @@ def _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, l
     rng = rng or (random.Random(_CONFIG["seed"]) if _CONFIG["seed"] is not None else random)
     out = {}
     pending = deque()       # (index, input, target, future of the label map), loader order
-    group = []              # sessions whose label map is in, waiting for a full batch
-    rows = [0]
+    # Sessions whose label map is in wait for a full batch PER KIND of staging (SaliencySession.stem: an image of 256+ rows takes the stem
+    # table, a smaller one K0 + the MFMA stem, and one forward takes one kind): a loader whose pictures straddle S = 254 then still runs
+    # full batches of each kind instead of two partial ones per group.  Results are EMITTED in loader order (the window draws of the
+    # reference happen image after image, generate_gp_training_data_imagenet.py:221-230: the draws of image i must not depend on how the
+    # images were grouped), so a scored session waits in `scored` until every earlier one has been scored too; MAX_WAITING bounds that
+    # queue when one kind is rare.
+    groups, rows = {}, {}   # kind -> sessions waiting for a full batch / their rows
+    scored = deque()        # (index, session), loader order, waiting for emission
+    MAX_WAITING = max(64, 4 * lookahead)
 
-    def flush():
-        ok = fill_tables(model, [s for _i, s in group])
-        for (idx, s), good in zip(group, ok):
-            if not good:
+    def drain():
+        while scored and scored[0][1].base_pred is not None:
+            idx, s = scored.popleft()
+            if s.base_pred != s.label:          # the reference's "wrong prediction" branch: no draws
                 out[idx] = None
                 continue
             firsts = masks.draw_first_indices(s.num_segments, n, rng)
             _score, table_pred = s.table()
             correct = np.array([table_pred[f] for f in firsts], dtype=np.int64) == s.label
             out[idx] = emit(idx, s, firsts, correct)
-        del group[:]
-        rows[0] = 0
+
+    def flush(kind=None):
+        for k in ([kind] if kind is not None else list(groups)):
+            if groups.get(k):
+                fill_tables(model, groups[k])
+                groups[k], rows[k] = [], 0
+        drain()
 
     def segmented(idx, x, target, fut):
         s = SaliencySession(model, x, target, segments=fut.result(), check_base=False)
-        group.append((idx, s))
-        rows[0] += s.num_segments + 2
-        if rows[0] >= model.max_batch:
+        groups.setdefault(s.stem, []).append(s)
+        rows[s.stem] = rows.get(s.stem, 0) + s.num_segments + 2
+        scored.append((idx, s))
+        if rows[s.stem] >= model.max_batch:
+            flush(s.stem)
+        if len(scored) > MAX_WAITING:
             flush()
 
     with segment.SegmenterPool(workers=workers) as pool:
@@ -377,8 +393,7 @@ def _many(val_loader, model, eval_img_indices, num_mask_samples, rng, workers, l
                 break
         while pending:
             segmented(*pending.popleft())
-        if group:
-            flush()
+        flush()
     return out
 
 

@@ -839,3 +839,89 @@ def test_bound_library_record_names_the_product_build(mpx_lib):
         _lib.LIB_PATH = saved
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"custom (probe library)"' in src and "lib_stamp_matches_tree" in src
+
+
+class _KindEngine:
+    """An engine double WITH the two stagings (stem_for_rows) and deterministic fake scores that depend on the image, the mask row and the
+    label only -- never on how rows were grouped -- for the plumbing of api._many."""
+    max_batch = 400
+
+    def __init__(self):
+        self.packed_calls = []          # per score_images call: the set of kinds of its images
+        self.single_calls = 0
+
+    def stem_for_rows(self, rows):
+        return "table" if rows >= 256 else "conv"
+
+    @staticmethod
+    def _rows(image, onoff, label):
+        tag = int(round(float(np.asarray(image).reshape(-1)[0]) * 1000))
+        w = (np.arange(onoff.shape[1]) * 7 + tag) % 13
+        h = (onoff.astype(np.int64) @ w + tag) % 11
+        score = (h.astype(np.float32) + 1) / 12
+        full = onoff.all(axis=1)
+        pred = np.where(full | (h % 3 != 0), 5 + tag % 3, 999).astype(np.int32)      # the unmasked row predicts class 5 + tag % 3
+        return score, pred
+
+    def predict(self, image):
+        tag = int(round(float(np.asarray(image).reshape(-1)[0]) * 1000))
+        return 5 + tag % 3, None
+
+    def score_masks(self, image, segments, onoff, label, stem=None):
+        self.single_calls += 1
+        assert stem == self.stem_for_rows(int(np.asarray(segments).max()) + 3)      # the session's kind: S + 2 rows
+        s, p = self._rows(image, onoff, label)
+        return onoff, s, p
+
+    def score_images(self, images, segments, onoffs, labels, stem=None):
+        self.packed_calls.append({self.stem_for_rows(len(o)) for o in onoffs})
+        return [self._rows(im, o, lb) for im, o, lb in zip(images, onoffs, labels)]
+
+    def heatmap(self, seg_rank, onoff, pred, label):
+        return scorer.summed_superpixel_labels(seg_rank, onoff, np.asarray(pred) == label)
+
+
+def test_validate_many_groups_by_staging_and_emits_in_loader_order():
+    """api._many keeps one group of waiting sessions per kind of staging (a forward takes one kind) and still consumes the window draws
+    image after image in LOADER order: validate_many == validate() per image with one shared random stream, whatever the grouping; an image
+    whose unmasked prediction is wrong draws nothing, as upstream (generate_gp_training_data_imagenet.py:215,269-273)."""
+    maps = {}
+    sizes = [300, 60, 300, 40, 60, 300, 280, 50]
+    loader = []
+    for i, s_count in enumerate(sizes):
+        x = torch.zeros(1, 3, 224, 224)
+        x[0, 0, 0, 0] = (i + 1) / 1000.0            # the double's image tag
+        maps[i + 1] = (np.arange(224 * 224, dtype=np.int64) * s_count // (224 * 224)).reshape(224, 224).astype(np.int32)
+        good = i != 3                               # image 4 carries a wrong label
+        loader.append((x, torch.tensor([5 + (i + 1) % 3 if good else 77])))
+    # the label map of an image is handed out in CALL order (workers=1 keeps the pool's submission order = loader order)
+    calls = []
+
+    def segmenter_in_order(img_u8):
+        calls.append(1)
+        return maps[want_order[len(calls) - 1]]
+
+    idx = list(range(1, len(sizes) + 1))
+    api.configure(eval_img_index=1, num_mask_samples=9, segmenter=segmenter_in_order, mask_dir=None, seed=None)
+    try:
+        eng = _KindEngine()
+        want_order = idx
+        many = api.validate_many(loader, eng, None, idx, rng=random.Random(3), workers=1, lookahead=2)
+        assert all(len(k) == 1 for k in eng.packed_calls), eng.packed_calls           # one kind per packed call
+        assert {"table"} in eng.packed_calls and {"conv"} in eng.packed_calls
+        # the table group (302 / 302 / 302 / 282 rows, max_batch 400) fills twice; the conv group (62 + 42 + 62 + 52) only at the end
+        assert eng.packed_calls.count({"table"}) == 2 and eng.packed_calls.count({"conv"}) == 1
+        # per image, one shared stream, loader order
+        del calls[:]
+        eng2 = _KindEngine()
+        shared = random.Random(3)
+        want = {}
+        for i in idx:
+            want_order = [i]
+            del calls[:]
+            api.configure(eval_img_index=i, num_mask_samples=9, segmenter=segmenter_in_order, mask_dir=None, seed=None)
+            want[i] = api.validate(loader, eng2, None, i, rng=shared)
+        assert many[4] is None and want[4] == 0                                        # wrong base prediction: None / 0, no draws
+        assert {i: many[i] for i in idx if i != 4} == {i: want[i] for i in idx if i != 4}
+    finally:
+        api.configure(eval_img_index=1, num_mask_samples=100, segmenter=None, mask_dir=None, seed=None)
