@@ -2,7 +2,7 @@
 """Throughput of the reference-named entry (api.validate_summed_many) on N synthetic images: masked forwards per second with
 the window tables of consecutive images PACKED into full forward batches (api.fill_tables -> MaskedForwardEngine.score_images)
 and, for comparison, scored one image per forward (round 2's path: SaliencySession.table()).
-usage: python tools/api_throughput.py [arch] [images] [max_batch] [blobs|noise]   (felzenszwalb finds ~30 superpixels on the smooth
+usage: python tools/api_throughput.py [arch] [images] [max_batch] [blobs|noise|mixed]   (felzenszwalb finds ~30 superpixels on the smooth
 "blobs" pictures and ~330 on uniform noise; natural images lie between)"""
 import os
 import random
@@ -25,7 +25,11 @@ n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2340      # engine.whole_round_batch(2400)
 kind = sys.argv[4] if len(sys.argv) > 4 else "noise"
 eng = MaskedForwardEngine(arch, max_batch=max_batch, device=0).load_state_dict(synth.make_state_dict(arch))
-imgs = synth.make_images(n_img, seed=5, kind=kind)
+if kind == "mixed":      # noise pictures (S ~ 330: the stem table) and blobs pictures (S ~ 28: K0 + the MFMA stem) in turn: both kinds of staging in one loader
+    a, b = synth.make_images(n_img, seed=5, kind="noise"), synth.make_images(n_img, seed=5, kind="blobs")
+    imgs = np.stack([(a if i % 2 == 0 else b)[i] for i in range(n_img)])
+else:
+    imgs = synth.make_images(n_img, seed=5, kind=kind)
 xs = [scorer.to_tensor_normalize(im) for im in imgs]
 labels = [eng.predict(x)[0] for x in xs]
 loader = [(x[None], torch.tensor([l])) for x, l in zip(xs, labels)]
