@@ -59,3 +59,26 @@ def test_slic_label_maps_rank_like_np_unique():
         assert s == len(uniq) and rank.dtype == np.int32 and (uniq[rank] == seg).all()
         for f in (0, 1, s // 3, masks.bo_upper_bound(s)):
             assert (masks.expand_pixel_mask(rank, masks.window_onoff(s, f)) == scorer.window_mask_u8(seg, f)).all()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(0, 700), min_size=1, max_size=9), st.sampled_from([64, 257, 512, 1000]), st.sampled_from([None, "conv", "table"]))
+def test_score_images_packs_any_job_with_one_kind_per_forward(sizes, max_batch, stem):
+    """MaskedForwardEngine.score_images / score_packed over recorded kernel calls (tests/test_host_logic._StagingProbe: no library, no GPU):
+    for ANY mix of per-image row counts, batch size and `stem` argument every row comes back where it belongs, every image is staged by its
+    own row count (or by the caller's `stem`), no forward mixes the two kinds, no forward exceeds max_batch, and the number of forwards is
+    the least possible for one change of kind."""
+    from test_host_logic import _StagingProbe, _probe_job
+    eng = _StagingProbe(max_batch=max_batch)
+    out = eng.score_images(*_probe_job(sizes), **({} if stem is None else {"stem": stem}))
+    assert [len(s) for s, _p in out] == sizes
+    for i, (score, pred) in enumerate(out):
+        assert np.array_equal(score, i * 1000 + np.arange(sizes[i], dtype=np.float32))
+        kind = stem or ("table" if sizes[i] >= 256 else "conv")
+        assert (pred == (2 if kind == "table" else 1)).all()
+    assert all(len(k) == 1 and 0 < b <= max_batch for b, k in eng.forwards)
+    rows = {"table": 0, "conv": 0}
+    for m in sizes:
+        rows[stem or ("table" if m >= 256 else "conv")] += m
+    assert len(eng.forwards) == sum(-(-r // max_batch) for r in rows.values())
+    assert sorted(eng.builds) == sorted(i for i, m in enumerate(sizes) if m and (stem or ("table" if m >= 256 else "conv")) == "table")
